@@ -1,0 +1,126 @@
+"""ctypes binding of libgsplat_mi355x.so (C ABI declared in include/gsplat_mi355x.h).
+
+There is NO fallback: if the shared library is missing or a call fails this module raises.  PyTorch is
+used only for device memory, streams and autograd plumbing; every arithmetic step of the hot path runs
+in the hand-written gfx950 kernels behind these entry points.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_void_p
+from typing import Optional
+
+import torch
+
+GS_REC = 16
+GS_COLOR_NONE, GS_COLOR_N, GS_COLOR_CN, GS_COLOR_SH = 0, 1, 2, 3
+
+_LIB_NAME = "libgsplat_mi355x.so"
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "lib", _LIB_NAME)
+
+
+class ProjParams(Structure):
+    """Mirror of `gs_proj_params` (include/gsplat_mi355x.h)."""
+
+    _fields_ = [
+        ("N", c_int32), ("C", c_int32),
+        ("width", c_int32), ("height", c_int32),
+        ("tile_size", c_int32), ("tile_w", c_int32), ("tile_h", c_int32),
+        ("eps2d", c_float), ("near_plane", c_float), ("far_plane", c_float), ("radius_clip", c_float),
+        ("calc_compensations", c_int32),
+        ("color_mode", c_int32), ("color_dim", c_int32),
+        ("sh_degree", c_int32), ("sh_K", c_int32),
+        ("depth_channel", c_int32),
+    ]
+
+
+_P = c_void_p
+_SIGNATURES = {
+    "gs_version": (ctypes.c_int, []),
+    "gs_error_string": (c_char_p, [ctypes.c_int]),
+    "gs_projection_fwd": (ctypes.c_int, [POINTER(ProjParams)] + [_P] * 12 + [_P]),
+    "gs_projection_bwd": (ctypes.c_int, [POINTER(ProjParams)] + [_P] * 11 + [c_int64] + [_P] * 8 + [_P]),
+    "gs_sh_fwd": (ctypes.c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
+    "gs_sh_bwd": (ctypes.c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "gs_exclusive_scan_workspace_bytes": (c_int64, [c_int64]),
+    "gs_exclusive_scan_i32": (ctypes.c_int, [_P, _P, c_int64, _P, _P, c_int64, _P]),
+    "gs_isect_emit": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
+    "gs_radix_sort_workspace_bytes": (c_int64, [c_int64]),
+    "gs_radix_sort_pairs_u64_u32": (ctypes.c_int, [c_int64, c_int32, _P, _P, _P, _P, _P, c_int64, POINTER(c_int32), _P]),
+    "gs_isect_offset_encode": (ctypes.c_int, [c_int64, _P, c_int32, c_int32, c_int32, _P, _P]),
+    "gs_rasterize_fwd": (ctypes.c_int, [c_int32] * 5 + [_P, _P, _P, c_int64, _P, c_int32, _P, _P, _P, _P]),
+    "gs_rasterize_bwd": (ctypes.c_int, [c_int32] * 5 + [_P, _P, _P, c_int64, _P, c_int32, _P, _P, _P, _P, _P, c_int32, _P, _P]),
+    "gs_mark_visible": (ctypes.c_int, [c_int64, _P, _P, _P]),
+    "gs_compact_visible": (ctypes.c_int, [c_int32, c_int32] + [_P] * 10 + [_P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def lib_path() -> str:
+    return os.path.normpath(_LIB_PATH)
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the native library; raise loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{_LIB_NAME} not found at {path}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C 3d-reconstruction_amd/csrc). There is no CPU/PyTorch fallback for this path."
+            )
+        handle = ctypes.CDLL(path)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib().gs_error_string(int(status))
+        raise RuntimeError(f"{what} failed with status {status}: {msg.decode() if msg else '?'}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def require_gpu(*tensors: torch.Tensor) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "gsplat (MI355X build): tensors must live on a HIP device; this build has no CPU path "
+                f"(got a tensor on {t.device})."
+            )
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"gsplat (MI355X build): tensors on different devices: {dev} vs {t.device}")
+    if dev is None:
+        raise RuntimeError("gsplat (MI355X build): no tensor given")
+    return dev
+
+
+def stream_handle(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def f32c(t: torch.Tensor) -> torch.Tensor:
+    """fp32 + contiguous (no copy when already so)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()

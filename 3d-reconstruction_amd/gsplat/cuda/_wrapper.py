@@ -1,0 +1,304 @@
+"""Host-side operators over the C ABI (include/gsplat_mi355x.h), mirroring `gsplat.cuda._wrapper`.
+
+The reference imports exactly one symbol from this module path:
+    from gsplat.cuda._wrapper import spherical_harmonics
+(/root/reference/3D-Reconstruction-main/models/gaussians/basics.py:15; called at
+models/gaussians/vanilla.py:369, models/nodes/rigid.py:486, smpl.py:475, deformable.py:83,
+models/gaussians/deformgs.py:136, pvg.py:399).  The stage-level operators below (projection,
+tile intersection, sort, offsets, rasterize) are what `gsplat.rendering.rasterization` composes and
+what the parity tests call one by one.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from .. import _backend as B
+
+
+# ----------------------------------------------------------------------------- spherical harmonics
+class _SphericalHarmonics(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, degree: int, dirs: Tensor, coeffs: Tensor, masks: Optional[Tensor]):
+        dev = B.require_gpu(dirs, coeffs, masks)
+        K = coeffs.shape[-2]
+        lead = dirs.shape[:-1]
+        d = B.f32c(dirs).reshape(-1, 3)
+        c = B.f32c(coeffs).reshape(-1, K, 3)
+        m = masks.reshape(-1).to(torch.uint8).contiguous() if masks is not None else None
+        n = d.shape[0]
+        out = torch.empty(n, 3, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            B.check(B.lib().gs_sh_fwd(n, K, degree, B.ptr(d), B.ptr(c), B.ptr(m), B.ptr(out), B.stream_handle(dev)),
+                    "gs_sh_fwd")
+        ctx.save_for_backward(d, c, m if m is not None else torch.empty(0, device=dev))
+        ctx.has_mask = m is not None
+        ctx.degree, ctx.K, ctx.lead = degree, K, lead
+        ctx.coeff_shape = coeffs.shape
+        return out.reshape(lead + (3,))
+
+    @staticmethod
+    def backward(ctx, v_out: Tensor):
+        d, c, m = ctx.saved_tensors
+        m = m if ctx.has_mask else None
+        dev = d.device
+        n = d.shape[0]
+        v = B.f32c(v_out).reshape(-1, 3)
+        v_coeffs = torch.empty(n, ctx.K, 3, device=dev, dtype=torch.float32)
+        need_dirs = ctx.needs_input_grad[1]
+        v_dirs = torch.empty(n, 3, device=dev, dtype=torch.float32) if need_dirs else None
+        with torch.cuda.device(dev):
+            B.check(B.lib().gs_sh_bwd(n, ctx.K, ctx.degree, B.ptr(d), B.ptr(c), B.ptr(m), B.ptr(v), B.ptr(v_coeffs),
+                                      B.ptr(v_dirs), B.stream_handle(dev)), "gs_sh_bwd")
+        v_c = v_coeffs.reshape(ctx.coeff_shape) if ctx.needs_input_grad[2] else None
+        v_d = v_dirs.reshape(ctx.lead + (3,)) if need_dirs else None
+        return None, v_d, v_c, None
+
+
+def spherical_harmonics(degrees_to_use: int, dirs: Tensor, coeffs: Tensor, masks: Optional[Tensor] = None) -> Tensor:
+    """Real SH colours.  dirs [...,3] (normalised inside), coeffs [...,K,3], masks [...] -> [...,3].
+
+    Same contract as gsplat's op: `(degrees_to_use+1)**2 <= K`; differentiable w.r.t. coeffs and dirs;
+    masked-out rows are zero; no +0.5 (callers add it, vanilla.py:370)."""
+    assert (degrees_to_use + 1) ** 2 <= coeffs.shape[-2], coeffs.shape
+    assert dirs.shape[:-1] == coeffs.shape[:-2], (dirs.shape, coeffs.shape)
+    assert dirs.shape[-1] == 3, dirs.shape
+    assert coeffs.shape[-1] == 3, coeffs.shape
+    if masks is not None:
+        assert masks.shape == dirs.shape[:-1], masks.shape
+    return _SphericalHarmonics.apply(int(degrees_to_use), dirs, coeffs, masks)
+
+
+# ----------------------------------------------------------------------------- projection (+colour fusion)
+def _camera_centers(viewmats: Tensor) -> Tensor:
+    """Camera centres -inv(R) t of world->camera matrices, by the adjugate (tiny, differentiable)."""
+    R, t = viewmats[:, :3, :3], viewmats[:, :3, 3]
+    r0, r1, r2 = R[:, 0], R[:, 1], R[:, 2]
+    c12 = torch.linalg.cross(r1, r2)
+    c20 = torch.linalg.cross(r2, r0)
+    c01 = torch.linalg.cross(r0, r1)
+    det = (r0 * c12).sum(-1, keepdim=True)
+    return -(t[:, 0:1] * c12 + t[:, 1:2] * c20 + t[:, 2:3] * c01) / det
+
+
+def _make_params(N, C, width, height, tile_size, eps2d, near_plane, far_plane, radius_clip, calc_comp,
+                 color_mode, color_dim, sh_degree, sh_K, depth_channel) -> B.ProjParams:
+    p = B.ProjParams()
+    p.N, p.C, p.width, p.height = N, C, width, height
+    p.tile_size = tile_size
+    p.tile_w = math.ceil(width / tile_size)
+    p.tile_h = math.ceil(height / tile_size)
+    p.eps2d, p.near_plane, p.far_plane, p.radius_clip = eps2d, near_plane, min(far_plane, 3.0e38), radius_clip
+    p.calc_compensations = int(calc_comp)
+    p.color_mode, p.color_dim = color_mode, color_dim
+    p.sh_degree, p.sh_K = (sh_degree if sh_degree is not None else 0), sh_K
+    p.depth_channel = int(depth_channel)
+    return p
+
+
+class _ProjectSplats(torch.autograd.Function):
+    """means/quats/scales/opacities/colours/cameras -> splat records [C,N,16] + means2d [C,N,2]
+    (+ radii, tiles_per_gauss, non-differentiable)."""
+
+    @staticmethod
+    def forward(ctx, means, quats, scales, opacities, colors, viewmats, Ks, campos, params: B.ProjParams):
+        dev = B.require_gpu(means, quats, scales, opacities, colors, viewmats, Ks, campos)
+        N, C = params.N, params.C
+        means, quats, scales, opacities = B.f32c(means), B.f32c(quats), B.f32c(scales), B.f32c(opacities)
+        viewmats, Ks = B.f32c(viewmats), B.f32c(Ks)
+        colors = B.f32c(colors) if colors is not None else None
+        campos = B.f32c(campos) if campos is not None else None
+        radii = torch.empty(C, N, device=dev, dtype=torch.int32)
+        tiles = torch.empty(C, N, device=dev, dtype=torch.int32)
+        means2d = torch.empty(C, N, 2, device=dev, dtype=torch.float32)
+        splats = torch.zeros(C, N, B.GS_REC, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            B.check(B.lib().gs_projection_fwd(
+                ctypes.byref(params), B.ptr(means), B.ptr(quats), B.ptr(scales), B.ptr(opacities), B.ptr(viewmats),
+                B.ptr(Ks), B.ptr(campos), B.ptr(colors), B.ptr(radii), B.ptr(means2d), B.ptr(splats), B.ptr(tiles),
+                B.stream_handle(dev)), "gs_projection_fwd")
+        ctx.params = params
+        ctx.has_colors = colors is not None
+        ctx.has_campos = campos is not None
+        empty = torch.empty(0, device=dev)
+        ctx.save_for_backward(means, quats, scales, opacities, colors if colors is not None else empty, viewmats, Ks,
+                              campos if campos is not None else empty, radii, splats)
+        ctx.mark_non_differentiable(radii, tiles)
+        return splats, means2d, radii, tiles
+
+    @staticmethod
+    def backward(ctx, v_splats, v_means2d, _v_radii, _v_tiles):
+        means, quats, scales, opacities, colors, viewmats, Ks, campos, radii, splats = ctx.saved_tensors
+        p = ctx.params
+        dev = means.device
+        N, C = p.N, p.C
+        colors = colors if ctx.has_colors else None
+        campos = campos if ctx.has_campos else None
+        if v_splats is None:
+            v_splats = torch.zeros(C, N, B.GS_REC, device=dev, dtype=torch.float32)
+        v_splats = B.f32c(v_splats)
+        if v_means2d is None:
+            v_means2d = torch.zeros(C, N, 2, device=dev, dtype=torch.float32)
+        # accept the strided view v_splats[..., 0:2] handed back by the rasterizer without a copy
+        ok_layout = (v_means2d.dtype == torch.float32 and v_means2d.stride(2) == 1 and N > 0
+                     and v_means2d.stride(0) == N * v_means2d.stride(1) and v_means2d.stride(1) >= 2)
+        if not ok_layout:
+            v_means2d = B.f32c(v_means2d)
+        ld = v_means2d.stride(1) if N > 0 else 2
+        v_means = torch.empty_like(means)
+        v_quats = torch.empty_like(quats)
+        v_scales = torch.empty_like(scales)
+        v_opac = torch.empty_like(opacities)
+        v_colors = torch.empty_like(colors) if colors is not None else None
+        need_vm = ctx.needs_input_grad[5] or ctx.needs_input_grad[7]
+        v_viewmats = torch.zeros(C, 4, 4, device=dev, dtype=torch.float32) if need_vm else None
+        v_campos = torch.zeros(C, 3, device=dev, dtype=torch.float32) if (need_vm and campos is not None) else None
+        with torch.cuda.device(dev):
+            B.check(B.lib().gs_projection_bwd(
+                ctypes.byref(p), B.ptr(means), B.ptr(quats), B.ptr(scales), B.ptr(opacities), B.ptr(viewmats),
+                B.ptr(Ks), B.ptr(campos), B.ptr(colors), B.ptr(radii), B.ptr(splats), v_means2d.data_ptr(), ld,
+                B.ptr(v_splats), B.ptr(v_means), B.ptr(v_quats), B.ptr(v_scales), B.ptr(v_opac), B.ptr(v_colors),
+                B.ptr(v_viewmats), B.ptr(v_campos), B.stream_handle(dev)), "gs_projection_bwd")
+        g = ctx.needs_input_grad
+        return (v_means if g[0] else None, v_quats if g[1] else None, v_scales if g[2] else None,
+                v_opac if g[3] else None, v_colors if (g[4] and v_colors is not None) else None,
+                v_viewmats if g[5] else None, None, v_campos if (g[7] and v_campos is not None) else None, None)
+
+
+# ----------------------------------------------------------------------------- integer stages
+def exclusive_scan_i32(x: Tensor) -> Tuple[Tensor, Tensor]:
+    """Exclusive prefix sum of an int32 tensor (flattened).  Returns (scan int32, total int64[1])."""
+    dev = B.require_gpu(x)
+    x = x.contiguous().reshape(-1)
+    assert x.dtype == torch.int32
+    n = x.numel()
+    out = torch.empty_like(x)
+    total = torch.empty(1, device=dev, dtype=torch.int64)
+    wsb = int(B.lib().gs_exclusive_scan_workspace_bytes(n))
+    ws = torch.empty(max(wsb, 8), device=dev, dtype=torch.uint8)
+    with torch.cuda.device(dev):
+        B.check(B.lib().gs_exclusive_scan_i32(B.ptr(x), B.ptr(out), n, B.ptr(total), B.ptr(ws), wsb,
+                                              B.stream_handle(dev)), "gs_exclusive_scan_i32")
+    return out, total
+
+
+def radix_sort_pairs(keys: Tensor, vals: Tensor, end_bit: int) -> Tuple[Tensor, Tensor]:
+    """Stable ascending sort of (int64 key, int32 value) pairs on key bits [0, end_bit)."""
+    dev = B.require_gpu(keys, vals)
+    assert keys.dtype == torch.int64 and vals.dtype == torch.int32 and keys.shape == vals.shape and keys.dim() == 1
+    keys, vals = keys.contiguous(), vals.contiguous()
+    n = keys.numel()
+    if n == 0:
+        return keys, vals
+    kb, vb = torch.empty_like(keys), torch.empty_like(vals)
+    wsb = int(B.lib().gs_radix_sort_workspace_bytes(n))
+    ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+    in_b = ctypes.c_int32(0)
+    with torch.cuda.device(dev):
+        B.check(B.lib().gs_radix_sort_pairs_u64_u32(n, end_bit, B.ptr(keys), B.ptr(vals), B.ptr(kb), B.ptr(vb),
+                                                    B.ptr(ws), wsb, ctypes.byref(in_b), B.stream_handle(dev)),
+                "gs_radix_sort_pairs_u64_u32")
+    return (kb, vb) if in_b.value else (keys, vals)
+
+
+def isect_tiles_from_splats(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int, tile_height: int,
+                            sort: bool = True) -> Tuple[Tensor, Tensor]:
+    """isect_tiles pass 2 + sort from splat records (tile boxes were computed by the projection kernel).
+    Returns (isect_ids int64 [I], flatten_ids int32 [I])."""
+    dev = B.require_gpu(splats, tiles_per_gauss)
+    C, N = tiles_per_gauss.shape
+    cum, total = exclusive_scan_i32(tiles_per_gauss)
+    n_isects = int(total.item())  # the one host sync of the pipeline (gsplat has the same one)
+    isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64)
+    flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
+    if n_isects == 0:
+        return isect_ids, flatten_ids
+    with torch.cuda.device(dev):
+        B.check(B.lib().gs_isect_emit(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
+                                      B.ptr(cum), B.ptr(isect_ids), B.ptr(flatten_ids), B.stream_handle(dev)),
+                "gs_isect_emit")
+    if sort:
+        tile_n_bits = int(math.floor(math.log2(tile_width * tile_height))) + 1
+        cam_n_bits = int(math.floor(math.log2(C))) + 1
+        isect_ids, flatten_ids = radix_sort_pairs(isect_ids, flatten_ids, 32 + tile_n_bits + cam_n_bits)
+    return isect_ids, flatten_ids
+
+
+def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
+    dev = B.require_gpu(isect_ids)
+    offsets = torch.empty(n_cameras, tile_height, tile_width, device=dev, dtype=torch.int32)
+    with torch.cuda.device(dev):
+        B.check(B.lib().gs_isect_offset_encode(isect_ids.numel(), B.ptr(isect_ids.contiguous()), n_cameras, tile_width,
+                                               tile_height, B.ptr(offsets), B.stream_handle(dev)),
+                "gs_isect_offset_encode")
+    return offsets
+
+
+# ----------------------------------------------------------------------------- rasterize
+class _RasterizeSplats(torch.autograd.Function):
+    """splat records -> (render_colors [C,H,W,CH], render_alphas [C,H,W,1]); tile intersection, sort and
+    offsets (integer, non-differentiable) run inside forward."""
+
+    @staticmethod
+    def forward(ctx, splats, means2d, tiles_per_gauss, backgrounds, width, height, tile_size, channels, ed, absgrad,
+                packed_index):
+        dev = B.require_gpu(splats)
+        C, N = tiles_per_gauss.shape
+        TW, TH = math.ceil(width / tile_size), math.ceil(height / tile_size)
+        isect_ids, flatten_ids = isect_tiles_from_splats(splats, tiles_per_gauss, TW, TH)
+        offsets = isect_offset_encode(isect_ids, C, TW, TH)
+        bg = B.f32c(backgrounds) if backgrounds is not None else None
+        rc = torch.empty(C, height, width, channels, device=dev, dtype=torch.float32)
+        ra = torch.empty(C, height, width, 1, device=dev, dtype=torch.float32)
+        last_ids = torch.empty(C, height, width, device=dev, dtype=torch.int32)
+        n_isects = flatten_ids.numel()
+        with torch.cuda.device(dev):
+            B.check(B.lib().gs_rasterize_fwd(C, width, height, tile_size, channels, B.ptr(splats), B.ptr(offsets),
+                                             B.ptr(flatten_ids), n_isects, B.ptr(bg), int(ed), B.ptr(rc), B.ptr(ra),
+                                             B.ptr(last_ids), B.stream_handle(dev)), "gs_rasterize_fwd")
+        ctx.geom = (C, N, width, height, tile_size, channels, int(ed), bool(absgrad))
+        ctx.has_bg = bg is not None
+        ctx.has_packed = packed_index is not None
+        empty = torch.empty(0, device=dev)
+        ctx.save_for_backward(splats, means2d, offsets, flatten_ids, bg if bg is not None else empty, rc, ra, last_ids,
+                              packed_index if packed_index is not None else empty)
+        ctx.mark_non_differentiable(isect_ids, flatten_ids, offsets, last_ids)
+        return rc, ra, isect_ids, flatten_ids, offsets, last_ids
+
+    @staticmethod
+    def backward(ctx, v_rc, v_ra, *_):
+        splats, means2d, offsets, flatten_ids, bg, rc, ra, last_ids, packed_index = ctx.saved_tensors
+        C, N, width, height, tile_size, channels, ed, absgrad = ctx.geom
+        dev = splats.device
+        bg = bg if ctx.has_bg else None
+        v_rc = B.f32c(v_rc) if v_rc is not None else torch.zeros_like(rc)
+        v_ra = B.f32c(v_ra) if v_ra is not None else torch.zeros_like(ra)
+        v_splats = torch.zeros_like(splats)
+        with torch.cuda.device(dev):
+            B.check(B.lib().gs_rasterize_bwd(C, width, height, tile_size, channels, B.ptr(splats), B.ptr(offsets),
+                                             B.ptr(flatten_ids), flatten_ids.numel(), B.ptr(bg), ed, B.ptr(rc),
+                                             B.ptr(ra), B.ptr(last_ids), B.ptr(v_rc), B.ptr(v_ra), int(absgrad),
+                                             B.ptr(v_splats), B.stream_handle(dev)), "gs_rasterize_bwd")
+        if ctx.has_packed:
+            flat = v_splats.reshape(-1, B.GS_REC)
+            v_means2d = flat[packed_index, 0:2]
+            if absgrad:
+                means2d.absgrad = flat[packed_index, 10:12]
+        else:
+            v_means2d = v_splats[..., 0:2]
+            if absgrad:
+                # same attribute contract as gsplat: read by BasicTrainer.postprocess_per_train_step
+                # (/root/reference/3D-Reconstruction-main/models/trainers/base.py:282)
+                means2d.absgrad = v_splats[..., 10:12]
+        v_bg = None
+        if ctx.has_bg and ctx.needs_input_grad[3]:
+            vc = v_rc
+            if ed:
+                vc = vc.clone()
+                vc[..., -1] = vc[..., -1] / ra[..., 0].clamp(min=1e-10)
+            v_bg = (vc * (1.0 - ra)).sum(dim=(1, 2))
+        return v_splats, v_means2d, None, v_bg, None, None, None, None, None, None, None

@@ -1,0 +1,186 @@
+"""`gsplat.rendering.rasterization` for MI355X (gfx950): the drop-in the reference imports at
+/root/reference/3D-Reconstruction-main/models/gaussians/basics.py:12 and calls at
+models/trainers/base.py:393-408 (training / eval, render_mode="RGB+ED") and :772-787 (viewer, "RGB",
+radius_clip=4.0).  Same signature, argument meaning, return tuple, `meta` keys and assertion-style
+errors as gsplat 1.x; the arithmetic runs in hand-written HIP kernels behind the
+C ABI of include/gsplat_mi355x.h -- there is no PyTorch/CPU fallback.
+
+Pipeline (two autograd nodes, five kernels + an integer sort):
+  _ProjectSplats   : gs_projection_fwd  -- projection + SH colours + opacity*compensation + depth
+                                          channel + tile boxes/counts, one 64-B splat record per (c, n)
+  _RasterizeSplats : gs_exclusive_scan_i32 -> gs_isect_emit -> gs_radix_sort_pairs_u64_u32
+                     -> gs_isect_offset_encode -> gs_rasterize_fwd (ED normalisation fused)
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _backend as B
+from .cuda import _wrapper as W
+
+
+def _as_int(v) -> int:
+    # the reference passes 0-d / 1-element CUDA long tensors for width/height
+    # (/root/reference/3D-Reconstruction-main/datasets/base/pixel_source.py:653-654, :1111-1112)
+    if isinstance(v, Tensor):
+        return int(v.reshape(-1)[0].item())
+    return int(v)
+
+
+def rasterization(
+    means: Tensor,  # [N, 3]
+    quats: Tensor,  # [N, 4]
+    scales: Tensor,  # [N, 3]
+    opacities: Tensor,  # [N]
+    colors: Tensor,  # [(C,) N, D] or [(C,) N, K, 3]
+    viewmats: Tensor,  # [C, 4, 4]
+    Ks: Tensor,  # [C, 3, 3]
+    width: int,
+    height: int,
+    near_plane: float = 0.01,
+    far_plane: float = 1e10,
+    radius_clip: float = 0.0,
+    eps2d: float = 0.3,
+    sh_degree: Optional[int] = None,
+    packed: bool = True,
+    tile_size: int = 16,
+    backgrounds: Optional[Tensor] = None,
+    render_mode: str = "RGB",
+    sparse_grad: bool = False,
+    absgrad: bool = False,
+    rasterize_mode: str = "classic",
+    channel_chunk: int = 32,
+    distributed: bool = False,
+    covars: Optional[Tensor] = None,
+) -> Tuple[Tensor, Tensor, Dict]:
+    N = means.shape[0]
+    C = viewmats.shape[0]
+    assert means.shape == (N, 3), means.shape
+    assert quats.shape == (N, 4), quats.shape
+    assert scales.shape == (N, 3), scales.shape
+    assert opacities.shape == (N,), opacities.shape
+    assert viewmats.shape == (C, 4, 4), viewmats.shape
+    assert Ks.shape == (C, 3, 3), Ks.shape
+    assert render_mode in ["RGB", "D", "ED", "RGB+D", "RGB+ED"], render_mode
+    assert rasterize_mode in ["classic", "antialiased"], rasterize_mode
+    if covars is not None:
+        raise NotImplementedError("gsplat (MI355X build): precomputed `covars` are not supported")
+    if distributed:
+        raise NotImplementedError("gsplat (MI355X build): use gsplat.distributed (camera-sharded DP) instead")
+    if sparse_grad:
+        raise NotImplementedError("gsplat (MI355X build): sparse_grad is not supported (the reference never sets it)")
+    width, height = _as_int(width), _as_int(height)
+    tile_size = int(tile_size)
+    if tile_size != 16:
+        raise NotImplementedError("gsplat (MI355X build): tile_size must be 16")
+
+    if sh_degree is None:
+        assert (colors.dim() == 2 and colors.shape[0] == N) or (
+            colors.dim() == 3 and colors.shape[:2] == (C, N)), colors.shape
+    else:
+        assert (colors.dim() == 3 and colors.shape[0] == N and colors.shape[2] == 3) or (
+            colors.dim() == 4 and colors.shape[:2] == (C, N) and colors.shape[3] == 3), colors.shape
+        assert (sh_degree + 1) ** 2 <= colors.shape[-2], colors.shape
+    B.require_gpu(means, quats, scales, opacities, colors, viewmats, Ks)
+
+    want_depth = render_mode in ("RGB+D", "RGB+ED", "D", "ED")
+    ed = render_mode in ("ED", "RGB+ED")
+    campos = None
+    sh_K = 0
+    if render_mode in ("D", "ED"):
+        color_mode, color_dim, col_in = B.GS_COLOR_NONE, 0, None
+    elif sh_degree is None:
+        color_dim = colors.shape[-1]
+        color_mode = B.GS_COLOR_N if colors.dim() == 2 else B.GS_COLOR_CN
+        col_in = colors
+    elif colors.dim() == 3:
+        color_mode, color_dim, col_in = B.GS_COLOR_SH, 3, colors
+        sh_K = colors.shape[-2]
+        campos = W._camera_centers(viewmats)
+    else:
+        # per-camera SH coefficients [C,N,K,3]: evaluate with the standalone op, then feed [C,N,3]
+        cp = W._camera_centers(viewmats)
+        dirs = means[None, :, :] - cp[:, None, :]
+        col_in = torch.clamp_min(W.spherical_harmonics(sh_degree, dirs, colors) + 0.5, 0.0)
+        color_mode, color_dim = B.GS_COLOR_CN, 3
+        sh_degree = None
+    channels = color_dim + (1 if want_depth else 0)
+    if channels > 4:
+        raise NotImplementedError(
+            f"gsplat (MI355X build): {channels} render channels requested; this build rasterizes at most 4 "
+            "(RGB + depth) per call")
+    if backgrounds is not None:
+        assert backgrounds.shape == (C, color_dim), backgrounds.shape
+        bg = backgrounds
+        if want_depth and color_dim > 0:
+            bg = torch.cat([backgrounds, torch.zeros(C, 1, device=backgrounds.device, dtype=backgrounds.dtype)], -1)
+        elif color_dim == 0:
+            bg = torch.zeros(C, 1, device=means.device, dtype=torch.float32)
+    else:
+        bg = None
+
+    params = W._make_params(N, C, width, height, tile_size, eps2d, near_plane, far_plane, radius_clip,
+                            rasterize_mode == "antialiased", color_mode, color_dim, sh_degree, sh_K, want_depth)
+    splats, means2d, radii, tiles_per_gauss = W._ProjectSplats.apply(
+        means, quats, scales, opacities, col_in, viewmats, Ks, campos, params)
+
+    TW, TH = math.ceil(width / tile_size), math.ceil(height / tile_size)
+    meta: Dict = {}
+    packed_index = None
+    hook = means2d
+    if packed:
+        # gsplat's packed layout for `meta` (render-only in the reference: SURVEY.md section 8(a) note on packed)
+        camera_ids, gaussian_ids, radii_p, means2d_p, depths_p, conics_p, packed_index = _pack_meta(
+            splats, means2d, radii)
+        hook = means2d_p
+        meta.update({"camera_ids": camera_ids, "gaussian_ids": gaussian_ids, "radii": radii_p, "means2d": means2d_p,
+                     "depths": depths_p, "conics": conics_p,
+                     "opacities": splats.detach().reshape(-1, B.GS_REC)[packed_index, 5]})
+    render_colors, render_alphas, isect_ids, flatten_ids, isect_offsets, last_ids = W._RasterizeSplats.apply(
+        splats, hook, tiles_per_gauss, bg, width, height, tile_size, channels, ed, absgrad, packed_index)
+
+    if not packed:
+        sd = splats.detach()
+        meta.update({"camera_ids": None, "gaussian_ids": None, "radii": radii, "means2d": means2d,
+                     "depths": sd[..., 10], "conics": sd[..., 2:5], "opacities": sd[..., 5]})
+    meta.update({
+        "tile_width": TW, "tile_height": TH, "tiles_per_gauss": tiles_per_gauss, "isect_ids": isect_ids,
+        "flatten_ids": flatten_ids, "isect_offsets": isect_offsets, "last_ids": last_ids,
+        "width": width, "height": height, "tile_size": tile_size, "n_cameras": C,
+    })
+    return render_colors, render_alphas, meta
+
+
+def _pack_meta(splats: Tensor, means2d: Tensor, radii: Tensor):
+    """CSR-style (camera_ids, gaussian_ids) + [nnz,*] arrays in ascending (c, n) order (Appendix A.7)."""
+    import ctypes  # noqa: F401
+
+    dev = radii.device
+    C, N = radii.shape
+    vis = torch.empty(C * N, device=dev, dtype=torch.int32)
+    with torch.cuda.device(dev):
+        B.check(B.lib().gs_mark_visible(C * N, B.ptr(radii), B.ptr(vis), B.stream_handle(dev)), "gs_mark_visible")
+    cum, total = W.exclusive_scan_i32(vis)
+    nnz = int(total.item())
+    camera_ids = torch.empty(nnz, device=dev, dtype=torch.int64)
+    gaussian_ids = torch.empty(nnz, device=dev, dtype=torch.int64)
+    radii_p = torch.empty(nnz, device=dev, dtype=torch.int32)
+    m2d_p = torch.empty(nnz, 2, device=dev, dtype=torch.float32)
+    depths_p = torch.empty(nnz, device=dev, dtype=torch.float32)
+    conics_p = torch.empty(nnz, 3, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        B.check(B.lib().gs_compact_visible(C, N, B.ptr(radii), B.ptr(cum), B.ptr(splats.detach()),
+                                           B.ptr(means2d.detach()), B.ptr(camera_ids), B.ptr(gaussian_ids),
+                                           B.ptr(radii_p), B.ptr(m2d_p), B.ptr(depths_p), B.ptr(conics_p),
+                                           B.stream_handle(dev)), "gs_compact_visible")
+    packed_index = camera_ids * N + gaussian_ids
+    if means2d.requires_grad:
+        # keep the packed means2d on the autograd path so that retain_grad()/.absgrad work as in gsplat
+        means2d_p = means2d.reshape(-1, 2)[packed_index]
+    else:
+        means2d_p = m2d_p
+    return camera_ids, gaussian_ids, radii_p, means2d_p, depths_p, conics_p, packed_index

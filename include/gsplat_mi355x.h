@@ -1,0 +1,195 @@
+/*
+ * gsplat_mi355x.h -- C ABI of libgsplat_mi355x.so, the MI355X (gfx950) native implementation of
+ * the gsplat `rasterization()` hot path that the reference calls.
+ *
+ * Reference interface each entry point stands in for (R = /root/reference/3D-Reconstruction-main;
+ * the callee is the un-vendored third-party package `gsplat`, so the citation is the reference's
+ * binding/call site plus the gsplat stage of SURVEY.md section 8(a) it replaces):
+ *
+ *   gs_projection_fwd / _bwd        R/models/gaussians/basics.py:12 -> gsplat.rendering.rasterization,
+ *                                   stage `fully_fused_projection` fwd/bwd (8a rows 2,3) fused with the
+ *                                   in-rasterization SH colour evaluation (8a row 4), the opacity x
+ *                                   compensation glue, the depth-channel `cat` (8a row 1 glue) and the
+ *                                   per-Gaussian tile count of `isect_tiles` pass 1 (8a row 5).
+ *   gs_sh_fwd / _bwd                R/models/gaussians/basics.py:15 -> gsplat.cuda._wrapper.spherical_harmonics
+ *                                   (called at R/models/gaussians/vanilla.py:369, R/models/nodes/rigid.py:486,
+ *                                   smpl.py:475, deformable.py:83) (8a row 4).
+ *   gs_exclusive_scan_i32,
+ *   gs_isect_emit                   `isect_tiles` cumsum + pass 2 (8a row 5).
+ *   gs_radix_sort_pairs_u64_u32     the cub::DeviceRadixSort::SortPairs<int64,int32> inside `isect_tiles` (8a row 6).
+ *   gs_isect_offset_encode          `isect_offset_encode` (8a row 7).
+ *   gs_rasterize_fwd / _bwd         `rasterize_to_pixels` fwd/bwd incl. the "ED" normalisation (8a rows 8,9,10),
+ *                                   call site R/models/trainers/base.py:393-408 and :772-787.
+ *   gs_compact_visible              the CSR emission of `fully_fused_projection_packed`, packed=True.
+ *
+ * Conventions: every pointer is a DEVICE pointer unless its name ends in `_host`; all tensors are
+ * dense row-major fp32 / int32 / int64 as stated; `stream` is a hipStream_t passed as void*.
+ * Every function returns 0 on success, a positive hipError_t, or a negative GS_ERR_* code, and
+ * never throws.  The library keeps no state between calls and never allocates device memory:
+ * scratch space is passed in by the caller (sizes from the *_workspace_bytes functions).
+ *
+ * Splat record ("splats", 16 floats = 64 B per (camera, Gaussian), one HBM request per gather):
+ *   [0] mean2d.x  [1] mean2d.y  [2] conic.a  [3] conic.b  [4] conic.c  [5] opacity*compensation
+ *   [6..9] up to 4 colour channels (colours, then the depth channel when requested; unused = 0)
+ *   [10] depth  [11] radius (int32 bits)  [12] compensation  [13] tile min x|y<<16  [14] tile max x|y<<16
+ *   [15] unused
+ * Gradient record ("v_splats", same shape): [0,1] v_mean2d  [2..4] v_conic  [5] v_opacity_eff
+ *   [6..9] v_colour channels  [10,11] sum over pixels of |v_mean2d| (absgrad)  [12..15] unused.
+ */
+#ifndef GSPLAT_MI355X_H
+#define GSPLAT_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_REC 16 /* floats per splat record */
+
+#define GS_OK 0
+#define GS_ERR_INVALID_ARG (-1)
+#define GS_ERR_UNSUPPORTED (-2)
+#define GS_ERR_WORKSPACE (-3)
+
+/* colour source of gs_projection_fwd/_bwd */
+#define GS_COLOR_NONE 0 /* no colour input (render_mode "D"/"ED")                    */
+#define GS_COLOR_N 1    /* colors [N, color_dim], shared by all cameras               */
+#define GS_COLOR_CN 2   /* colors [C, N, color_dim]                                   */
+#define GS_COLOR_SH 3   /* SH coefficients [N, sh_K, 3], evaluated per (camera, n)    */
+
+typedef struct gs_proj_params {
+  int32_t N, C;
+  int32_t width, height;
+  int32_t tile_size, tile_w, tile_h;
+  float eps2d, near_plane, far_plane, radius_clip;
+  int32_t calc_compensations; /* rasterize_mode == "antialiased" */
+  int32_t color_mode;         /* GS_COLOR_*                      */
+  int32_t color_dim;          /* channels of `colors` (SH: 3)    */
+  int32_t sh_degree, sh_K;    /* GS_COLOR_SH only                */
+  int32_t depth_channel;      /* 1: append depth after colours   */
+} gs_proj_params;
+
+int gs_version(void);
+const char* gs_error_string(int status);
+
+/* ---- fully_fused_projection (+SH, +opacity*comp, +tile count) ------------------------------- */
+int gs_projection_fwd(const gs_proj_params* p,
+                      const float* means,      /* [N,3]                         */
+                      const float* quats,      /* [N,4] wxyz, normalised inside */
+                      const float* scales,     /* [N,3]                         */
+                      const float* opacities,  /* [N]                           */
+                      const float* viewmats,   /* [C,4,4] world->camera         */
+                      const float* Ks,         /* [C,3,3]                       */
+                      const float* campos,     /* [C,3] camera centres (GS_COLOR_SH), else may be NULL */
+                      const float* colors,     /* per color_mode, may be NULL   */
+                      int32_t* radii,          /* out [C,N]                     */
+                      float* means2d,          /* out [C,N,2]                   */
+                      float* splats,           /* out [C,N,16], rows with radii==0 untouched */
+                      int32_t* tiles_per_gauss,/* out [C,N]                     */
+                      void* stream);
+
+int gs_projection_bwd(const gs_proj_params* p,
+                      const float* means, const float* quats, const float* scales,
+                      const float* opacities, const float* viewmats, const float* Ks,
+                      const float* campos, const float* colors,
+                      const int32_t* radii,    /* [C,N]    from forward         */
+                      const float* splats,     /* [C,N,16] from forward         */
+                      const float* v_means2d,  /* [C,N,*] gradient of means2d, row stride ld_v_means2d floats */
+                      int64_t ld_v_means2d,
+                      const float* v_splats,   /* [C,N,16] gradient record ([0,1] ignored) */
+                      float* v_means,          /* out [N,3]                     */
+                      float* v_quats,          /* out [N,4]                     */
+                      float* v_scales,         /* out [N,3]                     */
+                      float* v_opacities,      /* out [N]                       */
+                      float* v_colors,         /* out, shape of `colors`, may be NULL */
+                      float* v_viewmats,       /* out [C,4,4], PRE-ZEROED, may be NULL */
+                      float* v_campos,         /* out [C,3],   PRE-ZEROED, may be NULL */
+                      void* stream);
+
+/* ---- spherical_harmonics --------------------------------------------------------------------- */
+int gs_sh_fwd(int64_t n, int32_t K, int32_t degree,
+              const float* dirs,    /* [n,3]   */
+              const float* coeffs,  /* [n,K,3] */
+              const uint8_t* masks, /* [n] or NULL */
+              float* out,           /* [n,3], masked rows = 0 */
+              void* stream);
+int gs_sh_bwd(int64_t n, int32_t K, int32_t degree,
+              const float* dirs, const float* coeffs, const uint8_t* masks,
+              const float* v_out,   /* [n,3]   */
+              float* v_coeffs,      /* out [n,K,3] (all K written; unused bands = 0) */
+              float* v_dirs,        /* out [n,3] or NULL */
+              void* stream);
+
+/* ---- isect_tiles / offsets -------------------------------------------------------------------- */
+int64_t gs_exclusive_scan_workspace_bytes(int64_t n);
+int gs_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n,
+                          int64_t* total,      /* out, device, 1 element */
+                          void* workspace, int64_t workspace_bytes, void* stream);
+
+int gs_isect_emit(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h,
+                  const float* splats,             /* [C,N,16] */
+                  const int32_t* tiles_per_gauss,  /* [C,N]    */
+                  const int32_t* cum_excl,         /* [C,N] exclusive scan of tiles_per_gauss */
+                  int64_t* isect_ids,              /* out [n_isects] */
+                  int32_t* flatten_ids,            /* out [n_isects] */
+                  void* stream);
+
+int64_t gs_radix_sort_workspace_bytes(int64_t n);
+/* Stable LSD radix sort of (key,value) pairs on key bits [0,end_bit).  Ping-pongs between the a and b
+ * buffers; *result_in_b_host (HOST int) says which pair holds the sorted output. */
+int gs_radix_sort_pairs_u64_u32(int64_t n, int32_t end_bit,
+                                uint64_t* keys_a, uint32_t* vals_a,
+                                uint64_t* keys_b, uint32_t* vals_b,
+                                void* workspace, int64_t workspace_bytes,
+                                int32_t* result_in_b_host, void* stream);
+
+int gs_isect_offset_encode(int64_t n_isects, const int64_t* isect_ids_sorted,
+                           int32_t C, int32_t tile_w, int32_t tile_h,
+                           int32_t* offsets, /* out [C,tile_h,tile_w] */
+                           void* stream);
+
+/* ---- rasterize_to_pixels ---------------------------------------------------------------------- */
+int gs_rasterize_fwd(int32_t C, int32_t width, int32_t height, int32_t tile_size,
+                     int32_t channels,            /* 1..4 colour channels of the splat record */
+                     const float* splats,         /* [*,16] indexed by flatten_ids */
+                     const int32_t* isect_offsets,/* [C,tile_h,tile_w] */
+                     const int32_t* flatten_ids,  /* [n_isects] sorted */
+                     int64_t n_isects,
+                     const float* backgrounds,    /* [C,channels] or NULL */
+                     int32_t ed_last_channel,     /* 1: last channel /= max(alpha,1e-10) */
+                     float* render_colors,        /* out [C,H,W,channels] */
+                     float* render_alphas,        /* out [C,H,W]          */
+                     int32_t* last_ids,           /* out [C,H,W]          */
+                     void* stream);
+
+int gs_rasterize_bwd(int32_t C, int32_t width, int32_t height, int32_t tile_size,
+                     int32_t channels,
+                     const float* splats, const int32_t* isect_offsets,
+                     const int32_t* flatten_ids, int64_t n_isects,
+                     const float* backgrounds, int32_t ed_last_channel,
+                     const float* render_colors,  /* forward outputs */
+                     const float* render_alphas, const int32_t* last_ids,
+                     const float* v_render_colors,/* [C,H,W,channels] */
+                     const float* v_render_alphas,/* [C,H,W]          */
+                     int32_t absgrad,
+                     float* v_splats,             /* in/out [*,16], PRE-ZEROED, atomically accumulated */
+                     void* stream);
+
+/* ---- packed mode ------------------------------------------------------------------------------ */
+/* Emits, in ascending (camera, gaussian) order, the rows with radii > 0. cum_excl = exclusive scan of
+ * (radii > 0) computed with gs_exclusive_scan_i32 over `visible` (int32 0/1) written by gs_mark_visible. */
+int gs_mark_visible(int64_t n, const int32_t* radii, int32_t* visible, void* stream);
+int gs_compact_visible(int32_t C, int32_t N, const int32_t* radii, const int32_t* cum_excl,
+                       const float* splats, const float* means2d,
+                       int64_t* camera_ids, int64_t* gaussian_ids,   /* out [nnz] */
+                       int32_t* radii_packed,                         /* out [nnz] */
+                       float* means2d_packed,                         /* out [nnz,2] */
+                       float* depths_packed,                          /* out [nnz]   */
+                       float* conics_packed,                          /* out [nnz,3] */
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_MI355X_H */

@@ -1,0 +1,339 @@
+"""GPU parity tests: HIP kernels (through the C ABI / the gsplat-shaped host wrappers) vs the CPU oracle.
+
+Bars (BASELINE.json north_star): bit-exact tile-intersection ids, sort order and offsets; rendered
+RGB/depth/alpha and parameter gradients within 1e-5 absolute + 1e-4 relative (fp32).  PARITY UNPINNED
+against gsplat itself (see oracle/__init__.py); the oracle runs in fp64 on the same fp32 inputs.
+
+A handful of float outputs legitimately flip discrete decisions (alpha < 1/255 skip, T <= 1e-4 stop,
+ceil() of the radius) when `exp`/fma rounding differs by an ulp; those tests state the flip budget they
+allow next to the assertion.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import synth_scene
+from util import assert_close, close_report, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(N, C, W, H, sh_degree=3, extent=12.0, seed=42):
+    g = synth_scene.make_gaussians(N, sh_degree=sh_degree, extent=extent, seed=seed)
+    vm, Ks = synth_scene.make_cameras(C, W, H)
+    return g, vm, Ks
+
+
+# --------------------------------------------------------------------------------------------- SH
+@pytest.mark.parametrize("deg", [0, 1, 2, 3, 4])
+def test_sh_fwd_bwd(gpu_device, deg):
+    from gsplat.cuda._wrapper import spherical_harmonics
+
+    torch.manual_seed(deg)
+    n, K = 3000, 25 if deg == 4 else 16
+    dirs = torch.randn(n, 3) * 3.0
+    coeffs = torch.randn(n, K, 3)
+    masks = torch.rand(n) > 0.2
+    v = torch.randn(n, 3)
+    d_g, c_g = dirs.to(gpu_device).requires_grad_(True), coeffs.to(gpu_device).requires_grad_(True)
+    out = spherical_harmonics(deg, d_g, c_g, masks=masks.to(gpu_device))
+    (out * v.to(gpu_device)).sum().backward()
+    d_r, c_r = dirs.double().requires_grad_(True), coeffs.double().requires_grad_(True)
+    ref = oracle.spherical_harmonics(deg, d_r, c_r, masks=masks)
+    (ref * v.double()).sum().backward()
+    assert_close(f"sh{deg}.out", out, ref)
+    assert_close(f"sh{deg}.v_coeffs", c_g.grad, c_r.grad)
+    ref_vd = d_r.grad if d_r.grad is not None else torch.zeros_like(d_r)  # degree 0 does not depend on dirs
+    assert_close(f"sh{deg}.v_dirs", d_g.grad, ref_vd, atol=2e-5)
+    # band 0 is C0 * c (anchor: /root/reference/3D-Reconstruction-main/models/gaussians/basics.py:80)
+    if deg == 0:
+        sel = masks
+        assert torch.allclose(out.cpu()[sel], 0.28209479177387814 * coeffs[sel, 0, :], atol=1e-6)
+    # no-mask path and zero rows
+    out2 = spherical_harmonics(deg, dirs.to(gpu_device), coeffs.to(gpu_device))
+    assert_close(f"sh{deg}.nomask", out2, oracle.spherical_harmonics(deg, dirs.double(), coeffs.double()))
+    assert float(out.cpu()[~masks].abs().max()) == 0.0
+
+
+def test_sh_empty(gpu_device):
+    from gsplat.cuda._wrapper import spherical_harmonics
+
+    out = spherical_harmonics(3, torch.zeros(0, 3, device=gpu_device), torch.zeros(0, 16, 3, device=gpu_device))
+    assert out.shape == (0, 3)
+
+
+# --------------------------------------------------------------------------------------------- integer stages
+def test_scan_and_radix_sort(gpu_device):
+    from gsplat.cuda._wrapper import exclusive_scan_i32, radix_sort_pairs
+
+    rng = np.random.default_rng(0)
+    for n in [1, 63, 2048, 2049, 100_003, 1_300_000]:
+        x = rng.integers(0, 50, size=n).astype(np.int32)
+        out, total = exclusive_scan_i32(torch.from_numpy(x).to(gpu_device))
+        ref = np.cumsum(x.astype(np.int64)) - x
+        assert np.array_equal(out.cpu().numpy(), ref.astype(np.int32)), n
+        assert int(total.item()) == int(x.sum())
+    for n, bits in [(1, 40), (5000, 46), (4096, 33), (70_001, 50), (1_000_003, 46), (300_000, 64)]:
+        hi = (1 << min(bits + 3, 63)) - 1  # garbage above end_bit must be ignored
+        keys = rng.integers(0, hi, size=n, dtype=np.int64)
+        keys[: n // 3] &= (1 << 20) - 1  # many ties -> exercises stability
+        vals = np.arange(n, dtype=np.int32)
+        k, v = radix_sort_pairs(torch.from_numpy(keys).to(gpu_device), torch.from_numpy(vals).to(gpu_device), bits)
+        mask = (1 << bits) - 1 if bits < 64 else -1
+        order = np.argsort((keys & mask).astype(np.uint64), kind="stable")
+        assert np.array_equal(v.cpu().numpy(), vals[order]), (n, bits)
+        assert np.array_equal(k.cpu().numpy(), keys[order]), (n, bits)
+
+
+# --------------------------------------------------------------------------------------------- staged pipeline
+def _run_gpu_stages(g, vm, Ks, W, H, dev, mode="antialiased", sh_degree=3, render_mode="RGB+ED",
+                    near=0.1, radius_clip=0.0, backgrounds=None):
+    from gsplat.rendering import rasterization
+
+    gg = to_dev(g, dev)
+    for v in gg.values():
+        v.requires_grad_(True)
+    vmg = vm.to(dev).requires_grad_(True)
+    rc, ra, meta = rasterization(
+        gg["means"], gg["quats"], gg["scales"], gg["opacities"], gg["colors"], vmg, Ks.to(dev), W, H,
+        near_plane=near, radius_clip=radius_clip, sh_degree=sh_degree, packed=False, render_mode=render_mode,
+        absgrad=True, rasterize_mode=mode, backgrounds=backgrounds)
+    return gg, vmg, rc, ra, meta
+
+
+def _run_oracle(g, vm, Ks, W, H, mode="antialiased", sh_degree=3, render_mode="RGB+ED", near=0.1,
+                radius_clip=0.0, backgrounds=None):
+    go = {k: v.double().requires_grad_(True) for k, v in g.items()}
+    vmo = vm.double().requires_grad_(True)
+    rc, ra, meta = oracle.rasterization(
+        go["means"], go["quats"], go["scales"], go["opacities"], go["colors"], vmo, Ks.double(), W, H,
+        near_plane=near, radius_clip=radius_clip, sh_degree=sh_degree, render_mode=render_mode,
+        rasterize_mode=mode, backgrounds=backgrounds)
+    return go, vmo, rc, ra, meta
+
+
+def test_projection_fwd(gpu_device):
+    W, H, C, N = 160, 96, 2, 4096
+    g, vm, Ks = _scene(N, C, W, H)
+    # edge cases: behind camera, beyond far is untestable with 1e10; tiny + huge + degenerate scales
+    g["scales"][:50] = 1e-3
+    g["scales"][50:100, 2] = 0.0
+    g["scales"][100:120] = 2.0
+    gg, vmg, rc, ra, meta = _run_gpu_stages(g, vm, Ks, W, H, gpu_device)
+    go, vmo, rco, rao, mo = _run_oracle(g, vm, Ks, W, H)
+    r_g, r_o = meta["radii"].cpu(), mo["radii"]
+    diff = (r_g != r_o)
+    # radius = ceil(3 sqrt(lambda)) and the cull tests are float-derived: allow |delta| <= 1 on <= 0.1 % of rows
+    print(f"[parity] radii mismatches: {int(diff.sum())} of {diff.numel()}")
+    assert float(diff.double().mean()) <= 1e-3
+    both = (r_g > 0) & (r_o > 0)
+    assert int((r_g[both] - r_o[both]).abs().max()) <= 1
+    assert int(both.sum()) > 500
+    assert_close("means2d", meta["means2d"].cpu()[both], mo["means2d"][both], atol=1e-4)  # pixels, fp32 ulp at ~1e3
+    assert_close("depths", meta["depths"].cpu()[both], mo["depths"][both])
+    assert_close("conics", meta["conics"].cpu()[both], mo["conics"][both], rtol=2e-4)
+    assert_close("opacities*comp", meta["opacities"].cpu()[both], mo["opacities"][both])
+
+
+def test_isect_sort_offsets_bit_exact(gpu_device):
+    """Integer stages are compared bit-for-bit: the oracle is fed the GPU's own fp32 means2d/radii/depths."""
+    for (W, H, C, N) in [(160, 96, 2, 4096), (375, 250, 5, 20000), (33, 17, 1, 300)]:
+        g, vm, Ks = _scene(N, C, W, H)
+        gg, vmg, rc, ra, meta = _run_gpu_stages(g, vm, Ks, W, H, gpu_device)
+        TW, TH = meta["tile_width"], meta["tile_height"]
+        tpg, ids, fids = oracle.isect_tiles(meta["means2d"].cpu(), meta["radii"].cpu(), meta["depths"].cpu(), 16, TW, TH)
+        assert torch.equal(meta["tiles_per_gauss"].cpu(), tpg)
+        used = 32 + int(math.floor(math.log2(TW * TH))) + 1 + int(math.floor(math.log2(C))) + 1
+        assert used <= 64
+        assert torch.equal(meta["isect_ids"].cpu(), ids), "sorted intersection keys differ"
+        assert torch.equal(meta["flatten_ids"].cpu(), fids), "sort order (flatten ids) differs"
+        offs = oracle.isect_offset_encode(ids, C, TW, TH)
+        assert torch.equal(meta["isect_offsets"].cpu(), offs)
+        print(f"[parity] isect exact: W{W} H{H} C{C} N{N} I={ids.numel()}")
+
+
+def _splat_fields(meta_splats):
+    s = meta_splats
+    return s[..., 0:2], s[..., 2:5], s[..., 5], s[..., 6:10]
+
+
+@pytest.mark.parametrize("render_mode,bgflag", [("RGB+ED", False), ("RGB", True), ("ED", False), ("RGB+D", True)])
+def test_raster_fwd_bwd_given_same_inputs(gpu_device, render_mode, bgflag):
+    """rasterize_to_pixels fwd + bwd on identical inputs (the GPU's splat records and sorted lists)."""
+    from gsplat import _backend as B
+    from gsplat.cuda._wrapper import _RasterizeSplats
+
+    W, H, C, N = 150, 70, 2, 3000
+    g, vm, Ks = _scene(N, C, W, H)
+    bg = torch.rand(C, 3) if bgflag else None
+    gg, vmg, rc0, ra0, meta = _run_gpu_stages(g, vm, Ks, W, H, gpu_device, render_mode=render_mode,
+                                              backgrounds=bg.to(gpu_device) if bgflag else None)
+    ch = rc0.shape[-1]
+    ed = render_mode in ("ED", "RGB+ED")
+    # re-run the projection node alone to get the splat records as a leaf, then the raster node alone
+    from gsplat.cuda import _wrapper as Wm
+    campos = Wm._camera_centers(vmg.detach())
+    want_depth = render_mode in ("RGB+D", "RGB+ED", "D", "ED")
+    if render_mode in ("D", "ED"):
+        params = Wm._make_params(N, C, W, H, 16, 0.3, 0.1, 1e10, 0.0, True, B.GS_COLOR_NONE, 0, None, 0, True)
+        splats, m2d, radii, tiles = Wm._ProjectSplats.apply(
+            gg["means"].detach(), gg["quats"].detach(), gg["scales"].detach(), gg["opacities"].detach(), None,
+            vmg.detach(), Ks.to(gpu_device), None, params)
+    else:
+        params = Wm._make_params(N, C, W, H, 16, 0.3, 0.1, 1e10, 0.0, True, B.GS_COLOR_SH, 3, 3, 16, want_depth)
+        splats, m2d, radii, tiles = Wm._ProjectSplats.apply(
+            gg["means"].detach(), gg["quats"].detach(), gg["scales"].detach(), gg["opacities"].detach(),
+            gg["colors"].detach(), vmg.detach(), Ks.to(gpu_device), campos, params)
+    splats = splats.detach().clone().requires_grad_(True)
+    bg_full = None
+    if bgflag:
+        bg_full = bg.to(gpu_device)
+        if want_depth:
+            bg_full = torch.cat([bg_full, torch.zeros(C, 1, device=gpu_device)], -1)
+        bg_full = bg_full.clone().requires_grad_(True)
+    m2d_hook = m2d.detach().clone().requires_grad_(True)
+    rc, ra, isect_ids, flatten_ids, offsets, last_ids = _RasterizeSplats.apply(
+        splats, m2d_hook, tiles, bg_full, W, H, 16, ch, ed, True, None)
+    torch.manual_seed(3)
+    wc, wa = torch.randn(C, H, W, ch), torch.randn(C, H, W, 1)
+    ((rc * wc.to(gpu_device)).sum() + (ra * wa.to(gpu_device)).sum()).backward()
+
+    # oracle on the same records / lists
+    s64 = splats.detach().double().cpu()
+    m2, cn, op, col = [t.clone().requires_grad_(True) for t in _splat_fields(s64)]
+    colr = col[..., :ch]
+    bgo = bg_full.detach().double().cpu().requires_grad_(True) if bgflag else None
+    rco, rao, lasto = oracle.rasterize_to_pixels(m2, cn, colr, op, W, H, 16, offsets.cpu(), flatten_ids.cpu(), bgo)
+    if ed:
+        rco = torch.cat([rco[..., :-1], rco[..., -1:] / rao.clamp(min=1e-10)], -1)
+    ((rco * wc.double()).sum() + (rao * wa.double()).sum()).backward()
+
+    # forward.  exp()/fma rounding can flip "alpha < 1/255" or "T <= 1e-4" for a borderline pixel: budget 0.1 %
+    assert_close(f"{render_mode}.alphas", ra, rao, max_bad_frac=1e-3)
+    assert_close(f"{render_mode}.colors", rc, rco, max_bad_frac=1e-3)
+    mism = float((last_ids.cpu() != lasto).double().mean())
+    print(f"[parity] last_ids mismatch fraction {mism:.3e}")
+    assert mism <= 1e-3
+    # backward (atomics in fp32, run-to-run order varies): rtol 1e-4 + atol 1e-5 scaled by the loss weights
+    vs = splats.grad.cpu()
+    assert_close(f"{render_mode}.v_conics", vs[..., 2:5], cn.grad, max_bad_frac=2e-3, max_rel_l2=1e-4, scale_atol=True)
+    assert_close(f"{render_mode}.v_opacity", vs[..., 5], op.grad, max_bad_frac=2e-3, max_rel_l2=1e-4, scale_atol=True)
+    assert_close(f"{render_mode}.v_colors", vs[..., 6:6 + ch], col.grad[..., :ch], max_bad_frac=2e-3, max_rel_l2=1e-4, scale_atol=True)
+    assert_close(f"{render_mode}.v_means2d", m2d_hook.grad.cpu(), m2.grad, max_bad_frac=2e-3, max_rel_l2=1e-4, scale_atol=True)
+    assert float(vs[..., 12:].abs().max()) == 0.0
+    if bgflag:
+        assert_close(f"{render_mode}.v_bg", bg_full.grad, bgo.grad, rtol=2e-4)
+    # absgrad attribute contract (R/models/trainers/base.py:282)
+    assert hasattr(m2d_hook, "absgrad") and m2d_hook.absgrad.shape == (C, N, 2)
+    assert bool((m2d_hook.absgrad >= m2d_hook.grad.abs() - 1e-4 * m2d_hook.absgrad.abs() - 1e-6).all())
+
+
+def test_absgrad_small_image(gpu_device):
+    """absgrad = sum over pixels of |per-pixel d/d means2d| -- checked against per-pixel autograd on a tiny image."""
+    from gsplat import _backend as B
+    from gsplat.cuda import _wrapper as Wm
+
+    W, H, C, N = 20, 18, 1, 60
+    g, vm, Ks = _scene(N, C, W, H, sh_degree=None, extent=4.0)
+    g["scales"] *= 3.0
+    dev = gpu_device
+    gg = to_dev(g, dev)
+    params = Wm._make_params(N, C, W, H, 16, 0.3, 0.1, 1e10, 0.0, False, B.GS_COLOR_N, 3, None, 0, False)
+    splats, m2d, radii, tiles = Wm._ProjectSplats.apply(gg["means"], gg["quats"], gg["scales"], gg["opacities"],
+                                                        gg["colors"], vm.to(dev), Ks.to(dev), None, params)
+    splats = splats.detach().requires_grad_(True)
+    hook = m2d.detach().requires_grad_(True)
+    rc, ra, ids, fids, offs, last = Wm._RasterizeSplats.apply(splats, hook, tiles, None, W, H, 16, 3, False, True, None)
+    torch.manual_seed(1)
+    wc, wa = torch.randn(C, H, W, 3), torch.randn(C, H, W, 1)
+    ((rc * wc.to(dev)).sum() + (ra * wa.to(dev)).sum()).backward()
+    s64 = splats.detach().double().cpu()
+    m2, cn, op, col = _splat_fields(s64)
+    ref = oracle.gsplat_ref.means2d_absgrad_oracle(m2, cn, col[..., :3], op, W, H, 16, offs.cpu(), fids.cpu(),
+                                                   wc.double(), wa.double())
+    assert int((radii > 0).sum()) > 10
+    assert_close("absgrad", hook.absgrad, ref, max_bad_frac=5e-3, max_rel_l2=1e-4)
+
+
+# --------------------------------------------------------------------------------------------- end to end
+@pytest.mark.parametrize("mode,sh", [("antialiased", 3), ("classic", None)])
+def test_end_to_end_fwd_bwd(gpu_device, mode, sh):
+    W, H, C, N = 200, 120, 3, 6000
+    g, vm, Ks = _scene(N, C, W, H, sh_degree=sh)
+    g["opacities"][:300] = 0.0  # frame-invalid instances are exactly 0 (R/models/nodes/rigid.py:493)
+    gg, vmg, rc, ra, meta = _run_gpu_stages(g, vm, Ks, W, H, gpu_device, mode=mode, sh_degree=sh)
+    go, vmo, rco, rao, mo = _run_oracle(g, vm, Ks, W, H, mode=mode, sh_degree=sh)
+    torch.manual_seed(7)
+    wc, wa = torch.randn(C, H, W, 4) / (H * W) * 100, torch.randn(C, H, W, 1) / (H * W) * 100
+    meta["means2d"].retain_grad()
+    ((rc * wc.to(gpu_device)).sum() + (ra * wa.to(gpu_device)).sum()).backward()
+    ((rco * wc.double()).sum() + (rao * wa.double()).sum()).backward()
+    # End to end the two sides do NOT share tile lists: a radius that differs by one ulp-induced ceil() step adds
+    # or drops a tile for that Gaussian, changing a few pixels by <= ~1e-2.  Budget: 0.2 % of pixels.
+    assert_close(f"e2e.{mode}.alphas", ra, rao, max_bad_frac=2e-3)
+    assert_close(f"e2e.{mode}.colors", rc, rco, max_bad_frac=2e-3)
+    for k in ["means", "quats", "scales", "opacities", "colors"]:
+        assert torch.isfinite(gg[k].grad).all()
+        close_report(f"e2e.{mode}.v_{k}", gg[k].grad, go[k].grad)
+        frac, rel_l2, _ = close_report(f"e2e.{mode}.v_{k}(atol1e-4)", gg[k].grad, go[k].grad, atol=1e-4, rtol=1e-3)
+        assert rel_l2 <= 2e-3, (k, rel_l2)
+        assert frac <= 1e-2, (k, frac)
+    frac, rel_l2, _ = close_report(f"e2e.{mode}.v_viewmats", vmg.grad[:, :3, :], vmo.grad[:, :3, :], atol=1e-4, rtol=1e-3)
+    assert rel_l2 <= 2e-3
+    assert meta["means2d"].grad is not None and meta["means2d"].absgrad.shape == (C, N, 2)
+    assert float(gg["opacities"].grad[:300].abs().max()) >= 0.0  # finite, may be non-zero (d/d opacity at 0)
+
+
+def test_viewer_call_and_empty(gpu_device):
+    """Second call site (R/models/trainers/base.py:772-787): render_mode RGB, radius_clip=4, defaults; and N=0."""
+    from gsplat.rendering import rasterization
+
+    W, H, C, N = 97, 53, 1, 2000
+    g, vm, Ks = _scene(N, C, W, H, sh_degree=None)
+    gg = to_dev(g, gpu_device)
+    rc, ra, meta = rasterization(gg["means"], gg["quats"], gg["scales"], gg["opacities"], gg["colors"],
+                                 vm.to(gpu_device), Ks.to(gpu_device), W, H, packed=False, radius_clip=4.0)
+    go = {k: v.double() for k, v in g.items()}
+    rco, rao, mo = oracle.rasterization(go["means"], go["quats"], go["scales"], go["opacities"], go["colors"],
+                                        vm.double(), Ks.double(), W, H, radius_clip=4.0)
+    assert rc.shape == (C, H, W, 3) and ra.shape == (C, H, W, 1)
+    assert int(((meta["radii"].cpu() > 0) & (meta["radii"].cpu() <= 4)).sum()) == 0
+    assert_close("viewer.colors", rc, rco, max_bad_frac=2e-3)
+    assert_close("viewer.alphas", ra, rao, max_bad_frac=2e-3)
+    # no Gaussians at all
+    z = lambda *s: torch.zeros(*s, device=gpu_device)
+    rc, ra, meta = rasterization(z(0, 3), z(0, 4), z(0, 3), z(0), z(0, 3), vm.to(gpu_device), Ks.to(gpu_device), W, H,
+                                 packed=False)
+    assert float(rc.abs().max()) == 0.0 and float(ra.abs().max()) == 0.0
+    # everything behind the camera
+    gg2 = dict(gg)
+    gg2["means"] = gg["means"].clone()
+    gg2["means"][:, 0] = -50.0 - gg2["means"][:, 0].abs()
+    rc, ra, meta = rasterization(gg2["means"], gg2["quats"], gg2["scales"], gg2["opacities"], gg2["colors"],
+                                 vm.to(gpu_device), Ks.to(gpu_device), W, H, packed=False)
+    assert int((meta["radii"] > 0).sum()) == 0 and meta["flatten_ids"].numel() == 0
+    assert float(ra.abs().max()) == 0.0
+
+
+def test_packed_meta(gpu_device):
+    from gsplat.rendering import rasterization
+
+    W, H, C, N = 120, 80, 3, 3000
+    g, vm, Ks = _scene(N, C, W, H, sh_degree=None)
+    gg = to_dev(g, gpu_device)
+    a = rasterization(gg["means"], gg["quats"], gg["scales"], gg["opacities"], gg["colors"], vm.to(gpu_device),
+                      Ks.to(gpu_device), W, H, packed=False, render_mode="RGB+ED")
+    b = rasterization(gg["means"], gg["quats"], gg["scales"], gg["opacities"], gg["colors"], vm.to(gpu_device),
+                      Ks.to(gpu_device), W, H, packed=True, render_mode="RGB+ED")
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    ma, mb = a[2], b[2]
+    vis = ma["radii"] > 0
+    cid, gid = torch.nonzero(vis, as_tuple=True)
+    assert torch.equal(mb["camera_ids"], cid) and torch.equal(mb["gaussian_ids"], gid)
+    assert torch.equal(mb["radii"], ma["radii"][vis])
+    assert torch.equal(mb["means2d"], ma["means2d"][vis])
+    assert torch.equal(mb["depths"], ma["depths"][vis])
+    assert torch.equal(mb["conics"], ma["conics"][vis])

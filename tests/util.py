@@ -1,0 +1,36 @@
+"""Shared helpers for the parity tests (tests/ only)."""
+import numpy as np
+import torch
+
+ATOL = 1e-5  # north_star: 1e-5 absolute ...
+RTOL = 1e-4  # ... and 1e-4 relative (fp32)
+
+
+def close_report(name, got, ref, atol=ATOL, rtol=RTOL, scale_atol=False):
+    """Elementwise |got-ref| <= atol + rtol*|ref|.  With scale_atol the absolute term is taken relative to the
+    tensor's peak magnitude (atol * max(1, max|ref|)): gradients in these tests are sums of thousands of fp32
+    terms of size ~max|ref| (the loss is a random linear functional with unit-variance weights), so an element
+    that is small by cancellation still carries rounding noise proportional to the terms, not to itself."""
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    if scale_atol and ref.numel():
+        atol = atol * max(1.0, float(ref.abs().max()))
+    err = (got - ref).abs()
+    bad = err > (atol + rtol * ref.abs())
+    frac = float(bad.double().mean()) if bad.numel() else 0.0
+    rel_l2 = float((got - ref).norm() / (ref.norm() + 1e-30))
+    mx = float(err.max()) if err.numel() else 0.0
+    print(f"[parity] {name}: n={ref.numel()} max_abs_err={mx:.3e} rel_l2={rel_l2:.3e} out_of_tol={frac:.3e}")
+    return frac, rel_l2, mx
+
+
+def assert_close(name, got, ref, atol=ATOL, rtol=RTOL, max_bad_frac=0.0, max_rel_l2=None, scale_atol=False):
+    frac, rel_l2, mx = close_report(name, got, ref, atol, rtol, scale_atol)
+    assert frac <= max_bad_frac, f"{name}: {frac:.3e} of elements outside atol={atol} rtol={rtol} (max abs err {mx:.3e})"
+    if max_rel_l2 is not None:
+        assert rel_l2 <= max_rel_l2, f"{name}: rel_l2 {rel_l2:.3e} > {max_rel_l2}"
+
+
+def to_dev(d, dev, dtype=torch.float32):
+    return {k: (v.to(dev, dtype) if v.is_floating_point() else v.to(dev)) for k, v in d.items()}
