@@ -119,6 +119,47 @@ def stream_handle(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+# ---- optional per-entry-point timing with HIP events on the launch stream (used by bench.py) ----------------
+_prof = None
+
+
+def profiling_start() -> None:
+    global _prof
+    _prof = {}
+
+
+def profiling_stop():
+    """Returns {entry point: (calls, mean ms)}; synchronises the device once."""
+    global _prof
+    rec, _prof = _prof, None
+    if not rec:
+        return {}
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in rec.items()}
+
+
+class timed:
+    """`with timed(name, device):` brackets a native launch with two events on the current stream."""
+
+    __slots__ = ("name", "dev", "a")
+
+    def __init__(self, name: str, dev: torch.device):
+        self.name, self.dev, self.a = name, dev, None
+
+    def __enter__(self):
+        if _prof is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record(torch.cuda.current_stream(self.dev))
+        return self
+
+    def __exit__(self, *exc):
+        if self.a is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record(torch.cuda.current_stream(self.dev))
+            _prof.setdefault(self.name, []).append((self.a, b))
+        return False
+
+
 def f32c(t: torch.Tensor) -> torch.Tensor:
     """fp32 + contiguous (no copy when already so)."""
     if t.dtype != torch.float32:

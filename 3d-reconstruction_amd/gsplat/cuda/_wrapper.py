@@ -32,7 +32,7 @@ class _SphericalHarmonics(torch.autograd.Function):
         m = masks.reshape(-1).to(torch.uint8).contiguous() if masks is not None else None
         n = d.shape[0]
         out = torch.empty(n, 3, device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), B.timed("gs_sh_fwd", dev):
             B.check(B.lib().gs_sh_fwd(n, K, degree, B.ptr(d), B.ptr(c), B.ptr(m), B.ptr(out), B.stream_handle(dev)),
                     "gs_sh_fwd")
         ctx.save_for_backward(d, c, m if m is not None else torch.empty(0, device=dev))
@@ -51,7 +51,7 @@ class _SphericalHarmonics(torch.autograd.Function):
         v_coeffs = torch.empty(n, ctx.K, 3, device=dev, dtype=torch.float32)
         need_dirs = ctx.needs_input_grad[1]
         v_dirs = torch.empty(n, 3, device=dev, dtype=torch.float32) if need_dirs else None
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), B.timed("gs_sh_bwd", dev):
             B.check(B.lib().gs_sh_bwd(n, ctx.K, ctx.degree, B.ptr(d), B.ptr(c), B.ptr(m), B.ptr(v), B.ptr(v_coeffs),
                                       B.ptr(v_dirs), B.stream_handle(dev)), "gs_sh_bwd")
         v_c = v_coeffs.reshape(ctx.coeff_shape) if ctx.needs_input_grad[2] else None
@@ -116,7 +116,7 @@ class _ProjectSplats(torch.autograd.Function):
         tiles = torch.empty(C, N, device=dev, dtype=torch.int32)
         means2d = torch.empty(C, N, 2, device=dev, dtype=torch.float32)
         splats = torch.zeros(C, N, B.GS_REC, device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), B.timed("gs_projection_fwd", dev):
             B.check(B.lib().gs_projection_fwd(
                 ctypes.byref(params), B.ptr(means), B.ptr(quats), B.ptr(scales), B.ptr(opacities), B.ptr(viewmats),
                 B.ptr(Ks), B.ptr(campos), B.ptr(colors), B.ptr(radii), B.ptr(means2d), B.ptr(splats), B.ptr(tiles),
@@ -157,7 +157,7 @@ class _ProjectSplats(torch.autograd.Function):
         need_vm = ctx.needs_input_grad[5] or ctx.needs_input_grad[7]
         v_viewmats = torch.zeros(C, 4, 4, device=dev, dtype=torch.float32) if need_vm else None
         v_campos = torch.zeros(C, 3, device=dev, dtype=torch.float32) if (need_vm and campos is not None) else None
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), B.timed("gs_projection_bwd", dev):
             B.check(B.lib().gs_projection_bwd(
                 ctypes.byref(p), B.ptr(means), B.ptr(quats), B.ptr(scales), B.ptr(opacities), B.ptr(viewmats),
                 B.ptr(Ks), B.ptr(campos), B.ptr(colors), B.ptr(radii), B.ptr(splats), v_means2d.data_ptr(), ld,
@@ -180,7 +180,7 @@ def exclusive_scan_i32(x: Tensor) -> Tuple[Tensor, Tensor]:
     total = torch.empty(1, device=dev, dtype=torch.int64)
     wsb = int(B.lib().gs_exclusive_scan_workspace_bytes(n))
     ws = torch.empty(max(wsb, 8), device=dev, dtype=torch.uint8)
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), B.timed("gs_exclusive_scan_i32", dev):
         B.check(B.lib().gs_exclusive_scan_i32(B.ptr(x), B.ptr(out), n, B.ptr(total), B.ptr(ws), wsb,
                                               B.stream_handle(dev)), "gs_exclusive_scan_i32")
     return out, total
@@ -198,7 +198,7 @@ def radix_sort_pairs(keys: Tensor, vals: Tensor, end_bit: int) -> Tuple[Tensor, 
     wsb = int(B.lib().gs_radix_sort_workspace_bytes(n))
     ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
     in_b = ctypes.c_int32(0)
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), B.timed("gs_radix_sort_pairs_u64_u32", dev):
         B.check(B.lib().gs_radix_sort_pairs_u64_u32(n, end_bit, B.ptr(keys), B.ptr(vals), B.ptr(kb), B.ptr(vb),
                                                     B.ptr(ws), wsb, ctypes.byref(in_b), B.stream_handle(dev)),
                 "gs_radix_sort_pairs_u64_u32")
@@ -217,7 +217,7 @@ def isect_tiles_from_splats(splats: Tensor, tiles_per_gauss: Tensor, tile_width:
     flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
     if n_isects == 0:
         return isect_ids, flatten_ids
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), B.timed("gs_isect_emit", dev):
         B.check(B.lib().gs_isect_emit(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
                                       B.ptr(cum), B.ptr(isect_ids), B.ptr(flatten_ids), B.stream_handle(dev)),
                 "gs_isect_emit")
@@ -231,7 +231,7 @@ def isect_tiles_from_splats(splats: Tensor, tiles_per_gauss: Tensor, tile_width:
 def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
     dev = B.require_gpu(isect_ids)
     offsets = torch.empty(n_cameras, tile_height, tile_width, device=dev, dtype=torch.int32)
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), B.timed("gs_isect_offset_encode", dev):
         B.check(B.lib().gs_isect_offset_encode(isect_ids.numel(), B.ptr(isect_ids.contiguous()), n_cameras, tile_width,
                                                tile_height, B.ptr(offsets), B.stream_handle(dev)),
                 "gs_isect_offset_encode")
@@ -256,7 +256,7 @@ class _RasterizeSplats(torch.autograd.Function):
         ra = torch.empty(C, height, width, 1, device=dev, dtype=torch.float32)
         last_ids = torch.empty(C, height, width, device=dev, dtype=torch.int32)
         n_isects = flatten_ids.numel()
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), B.timed("gs_rasterize_fwd", dev):
             B.check(B.lib().gs_rasterize_fwd(C, width, height, tile_size, channels, B.ptr(splats), B.ptr(offsets),
                                              B.ptr(flatten_ids), n_isects, B.ptr(bg), int(ed), B.ptr(rc), B.ptr(ra),
                                              B.ptr(last_ids), B.stream_handle(dev)), "gs_rasterize_fwd")
@@ -278,7 +278,7 @@ class _RasterizeSplats(torch.autograd.Function):
         v_rc = B.f32c(v_rc) if v_rc is not None else torch.zeros_like(rc)
         v_ra = B.f32c(v_ra) if v_ra is not None else torch.zeros_like(ra)
         v_splats = torch.zeros_like(splats)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), B.timed("gs_rasterize_bwd", dev):
             B.check(B.lib().gs_rasterize_bwd(C, width, height, tile_size, channels, B.ptr(splats), B.ptr(offsets),
                                              B.ptr(flatten_ids), flatten_ids.numel(), B.ptr(bg), ed, B.ptr(rc),
                                              B.ptr(ra), B.ptr(last_ids), B.ptr(v_rc), B.ptr(v_ra), int(absgrad),

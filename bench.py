@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpix/s fwd+bwd of the gsplat `rasterization()` hot path on MI355X.
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8(d) "Config 2"): 1,000,000 Gaussians, SH degree 3 (K = 16),
+5 cameras 1242x375 batched, render_mode "RGB+ED", absgrad + antialiased, packed=False; one step = SH + projection +
+tile intersection + sort + offsets + rasterize forward, a fixed random linear loss over colours and alphas, and the
+full backward to means / quats / scales / opacities / SH coefficients.  Synthetic scene (synth_scene.py, seed 42).
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+With N ranks every rank renders its own 5-camera frame of the same Gaussians (weak scaling: cameras/frames shard,
+section 8(e)) and the Gaussian-parameter gradients are SUM all-reduced over RCCL inside the timed region.
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "3d-reconstruction_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import synth_scene  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+
+
+def algorithmic_bytes(N, C, H, W, K, D, V, I, absgrad=True, aa=True):
+    """SURVEY.md section 8(d) per-stage algorithmic HBM bytes for one step (fp32)."""
+    P = C * H * W
+    T = C * ((H + 15) // 16) * ((W + 15) // 16)
+    b = {}
+    b["gs_projection_fwd"] = N * (12 + 12 * K) + V * 12 + N * 40 + C * N * 4 + V * (24 + (4 if aa else 0))
+    b["gs_exclusive_scan_i32+gs_isect_emit"] = V * 16 + I * 12
+    b["gs_radix_sort_pairs_u64_u32"] = I * 24
+    b["gs_isect_offset_encode"] = I * 8 + T * 4
+    b["gs_rasterize_fwd"] = I * (28 + 4 * D) + P * (4 * D + 8)
+    b["gs_rasterize_bwd"] = I * (28 + 4 * D) + P * (4 * D + 12) + V * (4 * D + 12 + 8 + 4 + (8 if absgrad else 0))
+    b["gs_projection_bwd"] = V * (24 + (4 if aa else 0)) + N * 40 + C * N * 4 + N * 40 + V * 12 + N * 12 + N * 12 * K
+    return b
+
+
+def cpu_baseline(threads: int):
+    """BASELINE.json configs[0]: the oracle (pure-PyTorch restatement of gsplat's algorithm) on host cores,
+    100k Gaussians, SH degree 3, one 1242x375 camera, one fwd+bwd (~10-20 s of CPU work)."""
+    import oracle
+
+    torch.set_num_threads(threads)
+    N, W, H = 100_000, 1242, 375
+    g = synth_scene.make_gaussians(N, sh_degree=3)
+    vm, Ks = synth_scene.make_cameras(1, W, H)
+    for v in g.values():
+        v.requires_grad_(True)
+    gen = torch.Generator().manual_seed(1)
+    wc = torch.randn(1, H, W, 4, generator=gen)
+    wa = torch.randn(1, H, W, 1, generator=gen)
+    t0 = time.perf_counter()
+    rc, ra, _ = oracle.rasterization(g["means"], g["quats"], g["scales"], g["opacities"], g["colors"], vm, Ks, W, H,
+                                     near_plane=0.1, sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased")
+    ((rc * wc).sum() + (ra * wa).sum()).backward()
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(W * H / dt / 1e6, 5), "unit": "Mpix/s", "cores": threads, "kind": "port",
+        "sample": f"configs[0]: 100k Gaussians, SH deg 3, one 1242x375 camera, 1 fwd+bwd in {dt:.1f} s (fp32, "
+                  f"torch CPU, {threads} threads)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--cams", type=int, default=5)
+    ap.add_argument("--width", type=int, default=1242)
+    ap.add_argument("--height", type=int, default=375)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=4)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1 and args.gpus == 1, (world, args.gpus)
+
+    from gsplat import _backend as B
+    from gsplat.distributed import all_reduce_gradients
+    from gsplat.rendering import rasterization
+
+    N, C, W, H, K, D = args.gaussians, args.cams, args.width, args.height, 16, 4
+    g = synth_scene.make_gaussians(N, sh_degree=3, seed=42)
+    params = {k: v.to(dev).requires_grad_(True) for k, v in g.items()}
+    # weak scaling: rank r renders frame r of the 5-camera rig (ego advances 0.5 m per frame)
+    vm, Ks = synth_scene.make_cameras(C, W, H, frame=rank)
+    vm, Ks = vm.to(dev), Ks.to(dev)
+    gen = torch.Generator().manual_seed(1 + rank)
+    wc = torch.randn(C, H, W, D, generator=gen).to(dev)
+    wa = torch.randn(C, H, W, 1, generator=gen).to(dev)
+    plist = list(params.values())
+
+    def step():
+        for p in plist:
+            p.grad = None
+        rc, ra, meta = rasterization(
+            params["means"], params["quats"], params["scales"], params["opacities"], params["colors"], vm, Ks, W, H,
+            near_plane=0.1, far_plane=1e10, sh_degree=3, packed=False, render_mode="RGB+ED", absgrad=True,
+            rasterize_mode="antialiased")
+        loss = (rc * wc).sum() + (ra * wa).sum()
+        loss.backward()
+        if world > 1:
+            all_reduce_gradients(plist)
+        return meta
+
+    for _ in range(args.warmup):
+        meta = step()
+    if args.warmup == 0:
+        meta = step()
+    V = int((meta["radii"] > 0).sum().item())
+    I = int(meta["flatten_ids"].numel())
+    del meta
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    B.profiling_start()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    kern = B.profiling_stop()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * C * H * W * args.steps / dt / 1e6
+        bytes_ = algorithmic_bytes(N, C, H, W, K, D, V, I)
+        kern_ms = {k: round(v[1], 4) for k, v in kern.items()}
+        kern_calls = {k: v[0] / args.steps for k, v in kern.items()}
+        dom = max(kern, key=lambda k: kern[k][1] * kern[k][0]) if kern else None
+        roofline = None
+        if dom is not None and dom in bytes_:
+            per_launch_ms = kern[dom][1]
+            ach = bytes_[dom] / (per_launch_ms * 1e-3) / 1e9
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                        "algorithmic_bytes_per_launch": bytes_[dom], "avg_launch_ms": round(per_launch_ms, 4)}
+        total_bytes = sum(bytes_.values())
+        out = {
+            "metric": "Mpix/s fwd+bwd, 1M Gaussians @375x1242x5 cams", "value": round(value, 3), "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 1M Gaussians, SH deg 3, 5 cams 1242x375 batched fwd+bwd, RGB+ED, "
+                                   "absgrad + antialiased, packed=False", "gaussians": N, "cams_per_gpu": C,
+                       "width": W, "height": H, "visible_pairs_V": V, "n_isects_I": I,
+                       "parallelism": f"camera/frame DP x{world}, grad all-reduce (RCCL)" if world > 1 else "single GPU"},
+            "roofline": roofline,
+            "step_hbm_floor": {"algorithmic_bytes_per_step": total_bytes,
+                               "frac_of_hbm_peak": round(total_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "kernels_ms": kern_ms, "kernel_calls_per_step": kern_calls,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_threads)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

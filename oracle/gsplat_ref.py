@@ -306,13 +306,17 @@ def rasterize_to_pixels(
     D = colors.shape[-1]
     dt = means2d.dtype
     ts = tile_size
-    m2 = means2d.reshape(-1, 2)
-    cn = conics.reshape(-1, 3)
-    col = colors.reshape(-1, D)
-    op = opacities.reshape(-1)
-    offs = isect_offsets.reshape(-1).tolist()
     n_isects = int(flatten_ids.shape[0])
     fids = flatten_ids.to(torch.int64)
+    n_tiles = C * TH * TW
+    offs = isect_offsets.reshape(-1).tolist() + [n_isects]
+    sizes = [offs[t + 1] - offs[t] for t in range(n_tiles)]
+    # gather every intersection's operands ONCE, then split per tile: keeps autograd's backward O(I)
+    # (a per-tile index/slice would zero-fill an [N]- or [I]-sized gradient per tile)
+    xy_t = torch.split(means2d.reshape(-1, 2)[fids], sizes)
+    co_t = torch.split(conics.reshape(-1, 3)[fids], sizes)
+    col_t = torch.split(colors.reshape(-1, D)[fids], sizes)
+    op_t = torch.split(opacities.reshape(-1)[fids], sizes)
 
     jj, ii = torch.meshgrid(torch.arange(ts), torch.arange(ts), indexing="xy")  # [ts,ts] x,y
     jj = jj.reshape(-1)
@@ -321,9 +325,9 @@ def rasterize_to_pixels(
     zero_col = torch.zeros(P, D, dtype=dt)
     one_T = torch.ones(P, dtype=dt)
     tiles_c, tiles_T, tiles_last = [], [], []
-    for t_lin in range(C * TH * TW):
+    for t_lin in range(n_tiles):
         s = offs[t_lin]
-        e = offs[t_lin + 1] if t_lin + 1 < C * TH * TW else n_isects
+        e = offs[t_lin + 1]
         tyi = (t_lin % (TH * TW)) // TW
         txi = t_lin % TW
         px = (txi * ts + jj).to(dt) + 0.5
@@ -335,13 +339,13 @@ def rasterize_to_pixels(
         last = torch.zeros(P, dtype=torch.int64)
         for cs in range(s, e, chunk):
             ce = min(e, cs + chunk)
-            g = fids[cs:ce]
-            xy = m2[g]
-            co = cn[g]
+            lo, hi = cs - s, ce - s
+            xy = xy_t[t_lin][lo:hi]
+            co = co_t[t_lin][lo:hi]
             dx = xy[None, :, 0] - px[:, None]
             dy = xy[None, :, 1] - py[:, None]
             sigma = 0.5 * (co[None, :, 0] * dx * dx + co[None, :, 2] * dy * dy) + co[None, :, 1] * dx * dy
-            alpha = torch.clamp(op[g][None, :] * torch.exp(-sigma), max=ALPHA_MAX)
+            alpha = torch.clamp(op_t[t_lin][lo:hi][None, :] * torch.exp(-sigma), max=ALPHA_MAX)
             valid = (sigma >= 0) & (alpha >= ALPHA_MIN)
             a_eff = torch.where(valid, alpha, torch.zeros_like(alpha))
             om = 1.0 - a_eff
@@ -350,7 +354,7 @@ def rasterize_to_pixels(
             stop = Tincl <= T_MIN
             include = valid & ~stop & ~done[:, None]
             w = torch.where(include, a_eff * Texcl, torch.zeros_like(a_eff))
-            out = out + w @ col[g]
+            out = out + w @ col_t[t_lin][lo:hi]
             T = T * torch.where(include, om, torch.ones_like(om)).prod(dim=1)
             kidx = torch.arange(cs, ce)[None, :].expand_as(include)
             last = torch.maximum(last, torch.where(include, kidx, torch.zeros_like(kidx)).max(dim=1).values)
