@@ -1,0 +1,138 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads and exports every symbol include/*.h declares,
+the gsplat module paths the reference imports exist, and the host wrappers validate arguments / fail loudly without
+a HIP device (no CPU fallback).  No compute calls are made here."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "gsplat_mi355x.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from gsplat import _backend as B
+
+    lib = ctypes.CDLL(B.lib_path())
+    declared = _declared_symbols()
+    assert len(declared) == 16, declared
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/gsplat_mi355x.h but not exported"
+    assert set(declared) == set(B.EXPORTED_SYMBOLS), set(declared) ^ set(B.EXPORTED_SYMBOLS)
+    assert B.lib().gs_version() >= 100
+    assert B.lib().gs_error_string(-2).decode().startswith("gsplat_mi355x")
+    # pure host-side entry points (no GPU needed)
+    assert B.lib().gs_exclusive_scan_workspace_bytes(5_000_000) >= 8 * (5_000_000 // 2048)
+    assert B.lib().gs_radix_sort_workspace_bytes(10_000_000) > 2 * 256 * 4 * (10_000_000 // 4096)
+
+
+def test_proj_params_struct_matches_header():
+    from gsplat import _backend as B
+
+    hdr = open(os.path.join(ROOT, "include", "gsplat_mi355x.h")).read()
+    body = re.search(r"typedef struct gs_proj_params \{(.*?)\} gs_proj_params;", hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        typ, names = decl.split(None, 1)
+        fields += [(n.strip(), typ) for n in names.split(",")]
+    got = [(n, {"c_int": "int32_t", "c_float": "float"}[t.__name__]) for n, t in B.ProjParams._fields_]
+    assert got == fields
+
+
+def test_reference_import_paths_exist():
+    # exactly the four imports of /root/reference/3D-Reconstruction-main/models/gaussians/basics.py:12-15
+    from gsplat.rendering import rasterization  # noqa: F401
+    from gsplat.cuda_legacy._wrapper import num_sh_bases  # noqa: F401
+    from gsplat.cuda_legacy._torch_impl import quat_to_rotmat  # noqa: F401
+    from gsplat.cuda._wrapper import spherical_harmonics  # noqa: F401
+    import inspect
+
+    sig = inspect.signature(rasterization)
+    names = list(sig.parameters)
+    assert names[:9] == ["means", "quats", "scales", "opacities", "colors", "viewmats", "Ks", "width", "height"]
+    for kw, default in [("near_plane", 0.01), ("far_plane", 1e10), ("radius_clip", 0.0), ("eps2d", 0.3),
+                        ("sh_degree", None), ("packed", True), ("tile_size", 16), ("backgrounds", None),
+                        ("render_mode", "RGB"), ("sparse_grad", False), ("absgrad", False),
+                        ("rasterize_mode", "classic"), ("channel_chunk", 32)]:
+        assert sig.parameters[kw].default == default, kw
+
+
+def test_no_cpu_fallback_and_shape_errors():
+    from gsplat.rendering import rasterization
+    from gsplat.cuda._wrapper import spherical_harmonics
+
+    N = 8
+    z = lambda *s: torch.zeros(*s)
+    args = dict(means=z(N, 3), quats=z(N, 4), scales=z(N, 3), opacities=z(N), colors=z(N, 3), viewmats=z(1, 4, 4),
+                Ks=z(1, 3, 3), width=32, height=32, packed=False)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        rasterization(**args)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        spherical_harmonics(1, z(N, 3), z(N, 4, 3))
+    bad = dict(args, opacities=z(N, 1))  # the reference squeezes [N,1] -> [N] itself (base.py:397)
+    with pytest.raises(AssertionError):
+        rasterization(**bad)
+    with pytest.raises(AssertionError):
+        rasterization(**dict(args, render_mode="RGBA"))
+    with pytest.raises(AssertionError):
+        spherical_harmonics(3, z(N, 3), z(N, 4, 3))  # (3+1)^2 > K
+    with pytest.raises(NotImplementedError):
+        rasterization(**dict(args, sparse_grad=True))
+
+
+def test_product_path_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "3d-reconstruction_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)
+
+
+def test_shard_views_partition():
+    from gsplat.distributed import shard_views
+
+    for n in [0, 1, 5, 8, 40, 600]:
+        for ws in [1, 2, 3, 8]:
+            got = [i for r in range(ws) for i in shard_views(n, r, ws)]
+            assert got == list(range(n))
+            sizes = [len(shard_views(n, r, ws)) for r in range(ws)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_camera_centers_and_saved_tensor_identity():
+    from gsplat.cuda._wrapper import _camera_centers
+    import synth_scene
+
+    vm, _ = synth_scene.make_cameras(5, 64, 48, dtype=torch.float64)
+    assert torch.allclose(_camera_centers(vm), torch.linalg.inv(vm)[:, :3, 3], atol=1e-12)
+
+    # the `.absgrad` contract relies on save_for_backward handing back the SAME python object for an input
+    class F(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, hook):
+            ctx.save_for_backward(hook)
+            return x * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            (hook,) = ctx.saved_tensors
+            hook.absgrad = g.abs()
+            return g * 2, g
+
+    a = torch.ones(3, requires_grad=True)
+    hook = a * 1.0
+    hook.retain_grad()
+    F.apply(a, hook).sum().backward()
+    assert hasattr(hook, "absgrad") and hook.grad is not None
