@@ -36,6 +36,29 @@ __device__ __forceinline__ TileGeom tile_geom(unsigned tile, int TW, int TH, uns
 }
 
 // ------------------------------------------------------------------------------------------ forward
+// LDS image of one staged splat (12 floats), conic pre-scaled by -log2(e) so that vis = exp2(power):
+//   q0 = {mx, my, A = -0.5*log2e*ca, B = -log2e*cb}   q1 = {C = -0.5*log2e*cc, opacity, c0, c1}   q2 = {c2, c3, -, -}
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ void stage_record(float4* sg, int lane, const float4& r0, const float4& r1, const float4& r2) {
+  sg[lane * 3 + 0] = make_float4(r0.x, r0.y, -0.5f * LOG2E * r0.z, -LOG2E * r0.w);
+  sg[lane * 3 + 1] = make_float4(-0.5f * LOG2E * r1.x, r1.y, r1.z, r1.w);
+  sg[lane * 3 + 2] = r2;
+}
+
+// exponent (in log2 units) of the Gaussian at the lane's 2x2 pixel quad; dx/dy are mean - pixel centre
+__device__ __forceinline__ void quad_power(const float4& q0, float Cc, float px0, float py0, float dx[2], float dy[2],
+                                           float pw[4]) {
+  dx[0] = q0.x - px0; dx[1] = dx[0] - 1.f;
+  dy[0] = q0.y - py0; dy[1] = dy[0] - 1.f;
+  const float ax0 = q0.z * dx[0], ax1 = q0.z * dx[1];
+  const float cy0 = Cc * dy[0] * dy[0], cy1 = Cc * dy[1] * dy[1];
+  pw[0] = fmaf(dx[0], fmaf(q0.w, dy[0], ax0), cy0);
+  pw[1] = fmaf(dx[1], fmaf(q0.w, dy[0], ax1), cy0);
+  pw[2] = fmaf(dx[0], fmaf(q0.w, dy[1], ax0), cy1);
+  pw[3] = fmaf(dx[1], fmaf(q0.w, dy[1], ax1), cy1);
+}
+
 template <int CH>
 __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
     int C, int W, int H, int TW, int TH, const float* __restrict__ splats, const int32_t* __restrict__ offsets,
@@ -47,16 +70,14 @@ __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
   const TileGeom tg = tile_geom(tile, TW, TH, n_tiles, offsets, n_isects);
   const int lane = threadIdx.x;
   const int ix0 = tg.tx * 16 + 2 * (lane & 7), iy0 = tg.ty * 16 + 2 * (lane >> 3);
-  const float px[2] = {(float)ix0 + 0.5f, (float)ix0 + 1.5f};
-  const float py[2] = {(float)iy0 + 0.5f, (float)iy0 + 1.5f};
-  bool inside[4], done[4];
+  const float px0 = (float)ix0 + 0.5f, py0 = (float)iy0 + 0.5f;
+  // T > 0: pixel live.  T < 0: pixel stopped (or outside the image); |T| is its final transmittance.
   float T[4], acc[4][CH];
   int cur[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    inside[p] = (ix0 + (p & 1) < W) && (iy0 + (p >> 1) < H);
-    done[p] = !inside[p];
-    T[p] = 1.f;
+    const bool inside = (ix0 + (p & 1) < W) && (iy0 + (p >> 1) < H);
+    T[p] = inside ? 1.f : -1.f;
     cur[p] = 0;
 #pragma unroll
     for (int k = 0; k < CH; ++k) acc[p][k] = 0.f;
@@ -72,66 +93,62 @@ __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
     }
   };
   if (nbatch > 0) prefetch(0);
-  bool all_done = false;
+  bool all_done = __ballot(T[0] > 0.f || T[1] > 0.f || T[2] > 0.f || T[3] > 0.f) == 0ull;
   for (int b = 0; b < nbatch && !all_done; ++b) {
-    sg[lane * 3 + 0] = n0;
-    sg[lane * 3 + 1] = n1;
-    sg[lane * 3 + 2] = n2;
+    stage_record(sg, lane, n0, n1, n2);
     __syncthreads();
     if (b + 1 < nbatch) prefetch(b + 1);
     const int kbase = tg.start + b * 64;
     const int cnt = min(64, tg.end - kbase);
     for (int j = 0; j < cnt; ++j) {
-      const float4 a = sg[j * 3 + 0];   // mx my ca cb
-      const float4 bq = sg[j * 3 + 1];  // cc op c0 c1
-      const float4 cq = sg[j * 3 + 2];  // c2 c3 depth radius
-      const float dx[2] = {a.x - px[0], a.x - px[1]};
-      const float dy[2] = {a.y - py[0], a.y - py[1]};
-      const float qx[2] = {a.z * dx[0] * dx[0], a.z * dx[1] * dx[1]};
-      const float qy[2] = {bq.x * dy[0] * dy[0], bq.x * dy[1] * dy[1]};
-      float alpha[4];
-      bool valid[4];
-      bool any_valid = false;
+      const float4 q0 = sg[j * 3 + 0];
+      const float4 q1 = sg[j * 3 + 1];
+      float dx[2], dy[2], pw[4], alpha[4];
+      quad_power(q0, q1.x, px0, py0, dx, dy, pw);
+      bool use[4];
+      bool any_use = false;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        const float sigma = 0.5f * (qx[p & 1] + qy[p >> 1]) + a.w * dx[p & 1] * dy[p >> 1];
-        alpha[p] = fminf(ALPHA_MAX, bq.y * __expf(-sigma));
-        valid[p] = !done[p] && !(sigma < 0.f || alpha[p] < ALPHA_MIN);
-        any_valid |= valid[p];
+        alpha[p] = fminf(ALPHA_MAX, q1.y * __builtin_amdgcn_exp2f(pw[p]));
+        use[p] = (pw[p] <= 0.f) && (alpha[p] >= ALPHA_MIN) && (T[p] > 0.f);
+        any_use |= use[p];
       }
-      if (__ballot(any_valid) == 0ull) continue;
-      const float col[4] = {bq.z, bq.w, cq.x, cq.y};
-      bool lane_done = true;
+      if (__ballot(any_use) == 0ull) continue;
+      const float2 q2 = *reinterpret_cast<const float2*>(&sg[j * 3 + 2]);
+      const float col[4] = {q1.z, q1.w, q2.x, q2.y};
+      bool any_stop = false;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        const float nT = T[p] * (1.f - alpha[p]);
-        const bool stop = valid[p] && (nT <= T_MIN);
-        done[p] |= stop;
-        const bool use = valid[p] && !stop;
-        const float w = use ? alpha[p] * T[p] : 0.f;
+        const float nT = fmaf(-alpha[p], T[p], T[p]);
+        const bool go = use[p] && (nT > T_MIN);
+        const bool stop = use[p] && !(nT > T_MIN);
+        any_stop |= stop;
+        const float w = go ? alpha[p] * T[p] : 0.f;
 #pragma unroll
         for (int k = 0; k < CH; ++k) acc[p][k] = fmaf(col[k], w, acc[p][k]);
-        cur[p] = use ? (kbase + j) : cur[p];
-        T[p] = use ? nT : T[p];
-        lane_done &= done[p];
+        cur[p] = go ? (kbase + j) : cur[p];
+        T[p] = go ? nT : (stop ? -T[p] : T[p]);
       }
-      if (__ballot(!lane_done) == 0ull) { all_done = true; break; }
+      if (__ballot(any_stop) != 0ull) {
+        if (__ballot(T[0] > 0.f || T[1] > 0.f || T[2] > 0.f || T[3] > 0.f) == 0ull) { all_done = true; break; }
+      }
     }
     __syncthreads();
   }
 
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    if (!inside[p]) continue;
     const int x = ix0 + (p & 1), y = iy0 + (p >> 1);
+    if (!(x < W && y < H)) continue;
     const int64_t pix = ((int64_t)tg.cam * H + y) * W + x;
-    const float alpha_out = 1.f - T[p];
+    const float Tf = fabsf(T[p]);
+    const float alpha_out = 1.f - Tf;
     out_a[pix] = alpha_out;
     last_ids[pix] = cur[p];
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
       float v = acc[p][k];
-      if (backgrounds) v += T[p] * backgrounds[tg.cam * CH + k];
+      if (backgrounds) v += Tf * backgrounds[tg.cam * CH + k];
       if (ed && k == CH - 1) v = v / fmaxf(alpha_out, 1e-10f);
       out_c[pix * CH + k] = v;
     }
