@@ -35,30 +35,51 @@ __device__ __forceinline__ TileGeom tile_geom(unsigned tile, int TW, int TH, uns
   return g;
 }
 
-// ------------------------------------------------------------------------------------------ forward
-// LDS image of one staged splat (12 floats), conic pre-scaled by -log2(e) so that vis = exp2(power):
-//   q0 = {mx, my, A = -0.5*log2e*ca, B = -log2e*cb}   q1 = {C = -0.5*log2e*cc, opacity, c0, c1}   q2 = {c2, c3, -, -}
+// Workgroup -> tile map.  Workgroups b and b+8 share an XCD (observed round-robin dispatch), so runs of
+// RASTER_CHUNK consecutive tiles (neighbours gather the same splat records -> same 4 MiB L2) go to one XCD
+// and successive chunks rotate over the 8 XCDs, which keeps cheap regions (sky, a sparse camera) from
+// idling whole XCDs.  The grid is padded to a multiple of 8 * RASTER_CHUNK; surplus workgroups exit.
+constexpr unsigned RASTER_CHUNK = 16;
+__host__ __device__ inline unsigned raster_grid(unsigned n_tiles) {
+  const unsigned n_chunks = (n_tiles + RASTER_CHUNK - 1) / RASTER_CHUNK;
+  return ((n_chunks + 7u) / 8u) * 8u * RASTER_CHUNK;
+}
+__device__ __forceinline__ unsigned raster_tile_of(unsigned bid) {
+  const unsigned xcd = bid & 7u, idx = bid >> 3;
+  return ((idx / RASTER_CHUNK) * 8u + xcd) * RASTER_CHUNK + (idx % RASTER_CHUNK);
+}
+
+// LDS image of one staged splat, conic pre-scaled so that vis = exp2(pw) with
+//   pw(dx, dy) = A dx^2 + 2 Bh dx dy + C dy^2,   (A, Bh, C) = -0.5 * log2(e) * (conic a, b, c),  d = mean - pixel
+//   q0 = {mx, my, A, Bh}   q1 = {C, opacity, c0, c1}   q2 = {c2, c3, sorted index k | gaussian row, -}
 constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float CONIC_SCALE = -0.5f * LOG2E;
 
-__device__ __forceinline__ void stage_record(float4* sg, int lane, const float4& r0, const float4& r1, const float4& r2) {
-  sg[lane * 3 + 0] = make_float4(r0.x, r0.y, -0.5f * LOG2E * r0.z, -LOG2E * r0.w);
-  sg[lane * 3 + 1] = make_float4(-0.5f * LOG2E * r1.x, r1.y, r1.z, r1.w);
-  sg[lane * 3 + 2] = r2;
+// Exact (conservative) per-tile cull, done by ONE lane per splat at staging time: an upper bound of pw over the
+// tile's 16x16 pixel-centre rectangle [x0, x0+15] x [y0, y0+15].  pw is a negative-definite quadratic with its
+// maximum (0) at the mean, so the constrained maximum lies on a face nearest the mean: maximise the 1-D
+// quadratic on the face dx = clamp(0) and on the face dy = clamp(0) and take the larger.  A splat whose best
+// possible alpha in the tile is below 1/255 is skipped by every pixel anyway (A.5: `alpha < 1/255 -> continue`),
+// so dropping it here changes no output bit; `slack` covers the fp32 rounding of the per-pixel evaluation.
+__device__ __forceinline__ bool tile_may_touch(float mx, float my, float A, float Bh, float C, float opac, float x0,
+                                               float y0) {
+  const float dxh = mx - x0, dxl = dxh - 15.f;
+  const float dyh = my - y0, dyl = dyh - 15.f;
+  const float cx = fminf(fmaxf(0.f, dxl), dxh);
+  const float cy = fminf(fmaxf(0.f, dyl), dyh);
+  const float ys = fminf(fmaxf(-Bh * cx * __builtin_amdgcn_rcpf(C), dyl), dyh);
+  const float xs = fminf(fmaxf(-Bh * cy * __builtin_amdgcn_rcpf(A), dxl), dxh);
+  const float pX = A * cx * cx + 2.f * Bh * cx * ys + C * ys * ys;
+  const float pY = A * xs * xs + 2.f * Bh * xs * cy + C * cy * cy;
+  const float Dx = fmaxf(fabsf(dxl), fabsf(dxh)), Dy = fmaxf(fabsf(dyl), fabsf(dyh));
+  const float slack = 1e-5f * (fabsf(A) * Dx * Dx + fabsf(C) * Dy * Dy) + 1e-2f;
+  const float pmax = fminf(0.f, fmaxf(pX, pY) + slack);
+  // NaN/inf in a record (never produced by the projection for a visible row) -> keep, the pixel loop decides
+  return !(opac * __builtin_amdgcn_exp2f(pmax) < ALPHA_MIN * 0.999f);
 }
 
-// exponent (in log2 units) of the Gaussian at the lane's 2x2 pixel quad; dx/dy are mean - pixel centre
-__device__ __forceinline__ void quad_power(const float4& q0, float Cc, float px0, float py0, float dx[2], float dy[2],
-                                           float pw[4]) {
-  dx[0] = q0.x - px0; dx[1] = dx[0] - 1.f;
-  dy[0] = q0.y - py0; dy[1] = dy[0] - 1.f;
-  const float ax0 = q0.z * dx[0], ax1 = q0.z * dx[1];
-  const float cy0 = Cc * dy[0] * dy[0], cy1 = Cc * dy[1] * dy[1];
-  pw[0] = fmaf(dx[0], fmaf(q0.w, dy[0], ax0), cy0);
-  pw[1] = fmaf(dx[1], fmaf(q0.w, dy[0], ax1), cy0);
-  pw[2] = fmaf(dx[0], fmaf(q0.w, dy[1], ax0), cy1);
-  pw[3] = fmaf(dx[1], fmaf(q0.w, dy[1], ax1), cy1);
-}
-
+// ------------------------------------------------------------------------------------------ forward
 template <int CH>
 __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
     int C, int W, int H, int TW, int TH, const float* __restrict__ splats, const int32_t* __restrict__ offsets,
@@ -66,9 +87,12 @@ __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
     float* __restrict__ out_c, float* __restrict__ out_a, int32_t* __restrict__ last_ids) {
   __shared__ float4 sg[64 * 3];
   const unsigned n_tiles = (unsigned)(C * TW * TH);
-  const unsigned tile = xcd_remap(blockIdx.x, n_tiles);
+  const unsigned tile = raster_tile_of(blockIdx.x);
+  if (tile >= n_tiles) return;
   const TileGeom tg = tile_geom(tile, TW, TH, n_tiles, offsets, n_isects);
   const int lane = threadIdx.x;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const float x0 = (float)(tg.tx * 16) + 0.5f, y0 = (float)(tg.ty * 16) + 0.5f;
   const int ix0 = tg.tx * 16 + 2 * (lane & 7), iy0 = tg.ty * 16 + 2 * (lane >> 3);
   const float px0 = (float)ix0 + 0.5f, py0 = (float)iy0 + 0.5f;
   // T > 0: pixel live.  T < 0: pixel stopped (or outside the image); |T| is its final transmittance.
@@ -95,27 +119,43 @@ __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
   if (nbatch > 0) prefetch(0);
   bool all_done = __ballot(T[0] > 0.f || T[1] > 0.f || T[2] > 0.f || T[3] > 0.f) == 0ull;
   for (int b = 0; b < nbatch && !all_done; ++b) {
-    stage_record(sg, lane, n0, n1, n2);
+    const int kbase = tg.start + b * 64;
+    // stage: scale the conic, cull against the tile rectangle, compact (order preserved)
+    const float A = CONIC_SCALE * n0.z, Bh = CONIC_SCALE * n0.w, Cc = CONIC_SCALE * n1.x;
+    const bool keep = (kbase + lane < tg.end) && tile_may_touch(n0.x, n0.y, A, Bh, Cc, n1.y, x0, y0);
+    const unsigned long long kmask = __ballot(keep);
+    const int cnt = __popcll(kmask);
+    if (keep) {
+      const int pos = __popcll(kmask & lt_mask);
+      sg[pos * 3 + 0] = make_float4(n0.x, n0.y, A, Bh);
+      sg[pos * 3 + 1] = make_float4(Cc, n1.y, n1.z, n1.w);
+      sg[pos * 3 + 2] = make_float4(n2.x, n2.y, __int_as_float(kbase + lane), 0.f);
+    }
     __syncthreads();
     if (b + 1 < nbatch) prefetch(b + 1);
-    const int kbase = tg.start + b * 64;
-    const int cnt = min(64, tg.end - kbase);
     for (int j = 0; j < cnt; ++j) {
       const float4 q0 = sg[j * 3 + 0];
       const float4 q1 = sg[j * 3 + 1];
-      float dx[2], dy[2], pw[4], alpha[4];
-      quad_power(q0, q1.x, px0, py0, dx, dy, pw);
+      const float dx0 = q0.x - px0, dx1 = dx0 - 1.f;
+      const float dy0 = q0.y - py0, dy1 = dy0 - 1.f;
+      const float adx[2] = {q0.z * dx0, q0.z * dx1}, bdx[2] = {q0.w * dx0, q0.w * dx1};
+      const float bdy[2] = {q0.w * dy0, q0.w * dy1}, cdy[2] = {q1.x * dy0, q1.x * dy1};
+      const float dxv[2] = {dx0, dx1}, dyv[2] = {dy0, dy1};
+      float pw[4], alpha[4];
       bool use[4];
       bool any_use = false;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
+        const int i = p & 1, jy = p >> 1;
+        pw[p] = fmaf(dxv[i], adx[i] + bdy[jy], dyv[jy] * (bdx[i] + cdy[jy]));
         alpha[p] = fminf(ALPHA_MAX, q1.y * __builtin_amdgcn_exp2f(pw[p]));
         use[p] = (pw[p] <= 0.f) && (alpha[p] >= ALPHA_MIN) && (T[p] > 0.f);
         any_use |= use[p];
       }
       if (__ballot(any_use) == 0ull) continue;
-      const float2 q2 = *reinterpret_cast<const float2*>(&sg[j * 3 + 2]);
+      const float4 q2 = sg[j * 3 + 2];
       const float col[4] = {q1.z, q1.w, q2.x, q2.y};
+      const int kcur = __float_as_int(q2.z);
       bool any_stop = false;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
@@ -126,7 +166,7 @@ __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
         const float w = go ? alpha[p] * T[p] : 0.f;
 #pragma unroll
         for (int k = 0; k < CH; ++k) acc[p][k] = fmaf(col[k], w, acc[p][k]);
-        cur[p] = go ? (kbase + j) : cur[p];
+        cur[p] = go ? kcur : cur[p];
         T[p] = go ? nT : (stop ? -T[p] : T[p]);
       }
       if (__ballot(any_stop) != 0ull) {
@@ -200,6 +240,13 @@ __device__ __forceinline__ float reduce_scatter12(const float v[12], bool b3, bo
   return r;
 }
 
+// Backward (A.6), branch-free over the lane's 4 pixels.  Per pixel the running state is two scalars:
+//   T  transmittance in front of the splat being visited (T_final divided back by (1 - alpha) one splat at a time)
+//   E  = T_final * v_alpha_out' - sum_{splats behind} fac * <colour, v_out>     (so that
+//        v_alpha = T * <colour, v_out> + E / (1 - alpha); this replaces A.6's per-channel `buf` accumulator)
+// A pixel for which the splat is not valid (k > last id, sigma < 0, alpha < 1/255) gets alpha := 0, which turns
+// every update into an exact no-op (ra = 1, fac = 0, z = 0) without a branch.  Gradient sums are accumulated in
+// the scaled conic units and rescaled once per slot after the wave reduction (POST below).
 template <int CH, bool ABSGRAD>
 __global__ __launch_bounds__(64) void rasterize_bwd_kernel(
     int C, int W, int H, int TW, int TH, const float* __restrict__ splats, const int32_t* __restrict__ offsets,
@@ -207,12 +254,13 @@ __global__ __launch_bounds__(64) void rasterize_bwd_kernel(
     const float* __restrict__ out_c, const float* __restrict__ out_a, const int32_t* __restrict__ last_ids,
     const float* __restrict__ v_out_c, const float* __restrict__ v_out_a, float* __restrict__ v_splats) {
   __shared__ float4 sg[64 * 3];
-  __shared__ int32_t sid[64];
   const unsigned n_tiles = (unsigned)(C * TW * TH);
-  const unsigned tile = xcd_remap(blockIdx.x, n_tiles);
+  const unsigned tile = raster_tile_of(blockIdx.x);
+  if (tile >= n_tiles) return;
   const TileGeom tg = tile_geom(tile, TW, TH, n_tiles, offsets, n_isects);
   if (tg.end <= tg.start) return;
   const int lane = threadIdx.x;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
 
   // which of the 12 gradient slots does this lane hold after reduce_scatter12?  (self-calibrating)
@@ -223,36 +271,39 @@ __global__ __launch_bounds__(64) void rasterize_bwd_kernel(
     for (int i = 0; i < 12; ++i) probe[i] = (lane == 0) ? (float)(i + 1) : 0.f;
     slot = (int)reduce_scatter12(probe, b3, b2) - 1;
     if ((lane & 3) != 0) slot = -1;
+    if (!ABSGRAD && slot >= 10) slot = -1;
   }
+  // slot -> true-gradient scale: mean (0,1) and absgrad (10,11): 2 ln2; conic (2,3,4): -1/2, -1, -1/2; rest 1
+  float post = 1.f;
+  if (slot == 0 || slot == 1 || slot >= 10) post = 2.f * LN2;
+  if (slot == 2 || slot == 4) post = -0.5f;
+  if (slot == 3) post = -1.f;
 
+  const float x0 = (float)(tg.tx * 16) + 0.5f, y0 = (float)(tg.ty * 16) + 0.5f;
   const int ix0 = tg.tx * 16 + 2 * (lane & 7), iy0 = tg.ty * 16 + 2 * (lane >> 3);
-  const float px[2] = {(float)ix0 + 0.5f, (float)ix0 + 1.5f};
-  const float py[2] = {(float)iy0 + 0.5f, (float)iy0 + 1.5f};
-  bool inside[4];
-  float T[4], Tfa[4], buf[4][CH], vo[4][CH];
-  float bgdot[4];
+  const float px0 = (float)ix0 + 0.5f, py0 = (float)iy0 + 0.5f;
+  float T[4], E[4], vo[4][CH];
   int last[4];
-  int my_max = 0;
+  int my_max = -1;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int x = ix0 + (p & 1), y = iy0 + (p >> 1);
-    inside[p] = (x < W) && (y < H);
-    T[p] = 1.f; Tfa[p] = 0.f; last[p] = -1; bgdot[p] = 0.f;
+    T[p] = 1.f; E[p] = 0.f; last[p] = -1;
 #pragma unroll
-    for (int k = 0; k < CH; ++k) { buf[p][k] = 0.f; vo[p][k] = 0.f; }
-    if (inside[p]) {
+    for (int k = 0; k < CH; ++k) vo[p][k] = 0.f;
+    if ((x < W) && (y < H)) {
       const int64_t pix = ((int64_t)tg.cam * H + y) * W + x;
-      const float A = out_a[pix];
-      const float Tf = 1.f - A;
+      const float Aout = out_a[pix];
+      const float Tf = 1.f - Aout;
       float va = v_out_a[pix];
 #pragma unroll
       for (int k = 0; k < CH; ++k) vo[p][k] = v_out_c[pix * CH + k];
       if (ed) {
-        const float Ac = fmaxf(A, 1e-10f);
+        const float Ac = fmaxf(Aout, 1e-10f);
         const float ved = vo[p][CH - 1];
         const float edv = out_c[pix * CH + CH - 1];
         vo[p][CH - 1] = ved / Ac;
-        if (A >= 1e-10f) va -= ved * edv / Ac;
+        if (Aout >= 1e-10f) va -= ved * edv / Ac;
       }
       if (backgrounds) {
         float accum = 0.f;
@@ -261,12 +312,11 @@ __global__ __launch_bounds__(64) void rasterize_bwd_kernel(
         va -= accum;  // d(out)/dT * dT/dalpha folded: v_alpha gets -T_final*ra*accum
       }
       T[p] = Tf;
-      Tfa[p] = Tf * va;
+      E[p] = Tf * va;
       last[p] = last_ids[pix];
       my_max = max(my_max, last[p]);
     }
   }
-  (void)bgdot;
   // wave max of last ids
   int wmax = my_max;
 #pragma unroll
@@ -285,75 +335,79 @@ __global__ __launch_bounds__(64) void rasterize_bwd_kernel(
   };
   if (k_top >= tg.start) prefetch(k_top);
   for (int kb = k_top; kb >= tg.start; kb -= 64) {
-    sg[lane * 3 + 0] = n0;
-    sg[lane * 3 + 1] = n1;
-    sg[lane * 3 + 2] = n2;
-    sid[lane] = nid;
+    const float A = CONIC_SCALE * n0.z, Bh = CONIC_SCALE * n0.w, Cc = CONIC_SCALE * n1.x;
+    const bool keep = (kb - lane >= tg.start) && tile_may_touch(n0.x, n0.y, A, Bh, Cc, n1.y, x0, y0);
+    const unsigned long long kmask = __ballot(keep);
+    const int cnt = __popcll(kmask);
+    if (keep) {
+      const int pos = __popcll(kmask & lt_mask);
+      sg[pos * 3 + 0] = make_float4(n0.x, n0.y, A, Bh);
+      sg[pos * 3 + 1] = make_float4(Cc, n1.y, n1.z, n1.w);
+      sg[pos * 3 + 2] = make_float4(n2.x, n2.y, __int_as_float(kb - lane), __int_as_float(nid));
+    }
     __syncthreads();
     if (kb - 64 >= tg.start) prefetch(kb - 64);
-    const int cnt = min(64, kb - tg.start + 1);
     for (int j = 0; j < cnt; ++j) {
-      const int k = kb - j;
-      const float4 a = sg[j * 3 + 0];   // mx my ca cb
-      const float4 bq = sg[j * 3 + 1];  // cc op c0 c1
-      const float4 cq = sg[j * 3 + 2];  // c2 c3 depth radius
-      const float dx[2] = {a.x - px[0], a.x - px[1]};
-      const float dy[2] = {a.y - py[0], a.y - py[1]};
-      const float qx[2] = {a.z * dx[0] * dx[0], a.z * dx[1] * dx[1]};
-      const float qy[2] = {bq.x * dy[0] * dy[0], bq.x * dy[1] * dy[1]};
-      float alpha[4], vis[4];
+      const float4 q0 = sg[j * 3 + 0];  // mx my A Bh
+      const float4 q1 = sg[j * 3 + 1];  // C op c0 c1
+      const float4 q2 = sg[j * 3 + 2];  // c2 c3 k gid
+      const int k = __float_as_int(q2.z);
+      const float dx0 = q0.x - px0, dx1 = dx0 - 1.f;
+      const float dy0 = q0.y - py0, dy1 = dy0 - 1.f;
+      const float adx[2] = {q0.z * dx0, q0.z * dx1}, bdx[2] = {q0.w * dx0, q0.w * dx1};
+      const float bdy[2] = {q0.w * dy0, q0.w * dy1}, cdy[2] = {q1.x * dy0, q1.x * dy1};
+      const float dxv[2] = {dx0, dx1}, dyv[2] = {dy0, dy1};
+      float gx[4], gy[4], vis[4], ov[4], alpha[4];
       bool valid[4];
       bool any_valid = false;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        const float sigma = 0.5f * (qx[p & 1] + qy[p >> 1]) + a.w * dx[p & 1] * dy[p >> 1];
-        vis[p] = __expf(-sigma);
-        alpha[p] = fminf(ALPHA_MAX, bq.y * vis[p]);
-        valid[p] = (k <= last[p]) && !(sigma < 0.f || alpha[p] < ALPHA_MIN);
+        const int i = p & 1, jy = p >> 1;
+        gx[p] = adx[i] + bdy[jy];
+        gy[p] = bdx[i] + cdy[jy];
+        const float pw = fmaf(dxv[i], gx[p], dyv[jy] * gy[p]);
+        vis[p] = __builtin_amdgcn_exp2f(pw);
+        ov[p] = q1.y * vis[p];
+        alpha[p] = fminf(ALPHA_MAX, ov[p]);
+        valid[p] = (k <= last[p]) && (pw <= 0.f) && (alpha[p] >= ALPHA_MIN);
         any_valid |= valid[p];
       }
       if (__ballot(any_valid) == 0ull) continue;
-      const float col[4] = {bq.z, bq.w, cq.x, cq.y};
+      const float col[4] = {q1.z, q1.w, q2.x, q2.y};
       float g[12];
 #pragma unroll
       for (int i = 0; i < 12; ++i) g[i] = 0.f;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        if (valid[p]) {
-          const float ra = 1.f / (1.f - alpha[p]);
-          T[p] *= ra;
-          const float fac = alpha[p] * T[p];
-          float v_alpha = 0.f;
+        const int i = p & 1, jy = p >> 1;
+        const float ae = valid[p] ? alpha[p] : 0.f;
+        const float ra = __builtin_amdgcn_rcpf(1.f - ae);
+        T[p] *= ra;
+        const float fac = ae * T[p];
+        float cdot = col[0] * vo[p][0];
 #pragma unroll
-          for (int k2 = 0; k2 < CH; ++k2) {
-            g[6 + k2] = fmaf(fac, vo[p][k2], g[6 + k2]);
-            v_alpha += (col[k2] * T[p] - buf[p][k2] * ra) * vo[p][k2];
-            buf[p][k2] = fmaf(col[k2], fac, buf[p][k2]);
-          }
-          v_alpha += Tfa[p] * ra;
-          const float ov = bq.y * vis[p];
-          if (ov <= ALPHA_MAX) {
-            const float v_sigma = -ov * v_alpha;
-            const float ddx = dx[p & 1], ddy = dy[p >> 1];
-            g[2] = fmaf(0.5f * v_sigma * ddx, ddx, g[2]);
-            g[3] = fmaf(v_sigma * ddx, ddy, g[3]);
-            g[4] = fmaf(0.5f * v_sigma * ddy, ddy, g[4]);
-            const float vx = v_sigma * (a.z * ddx + a.w * ddy);
-            const float vy = v_sigma * (a.w * ddx + bq.x * ddy);
-            g[0] += vx;
-            g[1] += vy;
-            if constexpr (ABSGRAD) {
-              g[10] += fabsf(vx);
-              g[11] += fabsf(vy);
-            }
-            g[5] = fmaf(vis[p], v_alpha, g[5]);
-          }
+        for (int c = 1; c < CH; ++c) cdot = fmaf(col[c], vo[p][c], cdot);
+        const float v_alpha = fmaf(T[p], cdot, ra * E[p]);
+        E[p] = fmaf(-fac, cdot, E[p]);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) g[6 + c] = fmaf(fac, vo[p][c], g[6 + c]);
+        const float vag = (valid[p] && ov[p] <= ALPHA_MAX) ? v_alpha : 0.f;
+        g[5] = fmaf(vis[p], vag, g[5]);
+        const float z = ov[p] * vag;  // = -v_sigma
+        const float zdx = z * dxv[i], zdy = z * dyv[jy];
+        g[2] = fmaf(zdx, dxv[i], g[2]);
+        g[3] = fmaf(zdx, dyv[jy], g[3]);
+        g[4] = fmaf(zdy, dyv[jy], g[4]);
+        const float vx = z * gx[p], vy = z * gy[p];
+        g[0] += vx;
+        g[1] += vy;
+        if constexpr (ABSGRAD) {
+          g[10] += fabsf(vx);
+          g[11] += fabsf(vy);
         }
       }
       const float r = reduce_scatter12(g, b3, b2);
-      if (slot >= 0) {
-        if (ABSGRAD || slot < 10) atomicAdd(v_splats + (int64_t)sid[j] * REC + slot, r);
-      }
+      if (slot >= 0) atomicAdd(v_splats + (int64_t)__float_as_int(q2.w) * REC + slot, r * post);
     }
     __syncthreads();
   }
@@ -383,7 +437,7 @@ extern "C" int gs_rasterize_fwd(int32_t C, int32_t width, int32_t height, int32_
   if (n_isects > 0 && (!splats || !flatten_ids)) return GS_ERR_INVALID_ARG;
   const int TW = (width + 15) / 16, TH = (height + 15) / 16;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((unsigned)(C * TW * TH)), block(64);
+  dim3 grid(gs::raster_grid((unsigned)(C * TW * TH))), block(64);
   switch (channels) {
     case 1: GS_RF_LAUNCH(1); break;
     case 2: GS_RF_LAUNCH(2); break;
@@ -417,7 +471,7 @@ extern "C" int gs_rasterize_bwd(int32_t C, int32_t width, int32_t height, int32_
     return GS_ERR_INVALID_ARG;
   const int TW = (width + 15) / 16, TH = (height + 15) / 16;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((unsigned)(C * TW * TH)), block(64);
+  dim3 grid(gs::raster_grid((unsigned)(C * TW * TH))), block(64);
   switch (channels) {
     case 1: GS_RB_LAUNCH(1); break;
     case 2: GS_RB_LAUNCH(2); break;
