@@ -1,12 +1,17 @@
-// Stable LSD radix sort of (uint64 key, uint32 value) pairs on the low `end_bit` key bits.
+// Stable LSD radix sort of (uint64 key, uint32 value) pairs on the key bits [begin_bit, end_bit).
 // Replaces the cub::DeviceRadixSort::SortPairs<int64,int32> call inside gsplat's isect_tiles
-// (SURVEY.md section 8(a) row 6, Appendix A.3): ties keep emission order, i.e. ascending flatten id.
+// (SURVEY.md section 8(a) row 6, Appendix A.3): ties keep their input order.
 //
-// gfx950 design: 8-bit digits; per pass  (1) per-workgroup digit histogram (LDS atomics),
-// (2) exclusive scan of the digit-major [256][nblocks] table, (3) stable scatter.  The in-workgroup
-// ranking is wave64 match-any: eight 64-bit ballots give each lane the mask of lanes holding the same
-// digit, so a rank is one popcount and one per-wave LDS counter read -- no per-thread counter arrays.
-// Only the bits actually used by the (camera|tile|depth) key are sorted.  HBM-bound integer work.
+// gfx950 design.  Digits are up to 9 bits wide and the bit range is split evenly over the fewest passes
+// (35 key bits of the depth pre-sort -> 4 passes, 14 (camera|tile) bits -> 2 passes of 7).  Three launches per pass:
+//   (1) rs_hist     per-workgroup digit histogram into a digit-major table [radix][blocks]
+//   (2) rs_colscan  one wave per digit: exclusive scan of its table row over the blocks (+ the digit total)
+//   (3) rs_scatter  exclusive scan of the digit totals in LDS, stable ranking, scatter
+// In-workgroup ranking is wave64 match-any: nine 64-bit ballots give each lane the mask of lanes that hold the
+// same digit, so a rank is one popcount plus one per-wave LDS counter -- no per-thread counter arrays and no
+// LDS-atomic pile-up when a whole wave holds one digit (the (camera|tile) passes do).
+// The element count may live in device memory (`n_dev`): grids are sized for `n_max` and surplus workgroups exit,
+// which lets the host enqueue a sort whose size it does not know yet.  HBM-bound integer work.
 #include "gs_common.hpp"
 
 namespace gs {
@@ -15,59 +20,140 @@ constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = RS_THREADS / 64;
 constexpr int RS_ITEMS = 16;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 4096 keys per workgroup
-constexpr int RS_BITS = 8;
-constexpr int RS_RADIX = 1 << RS_BITS;
+constexpr int RS_MAX_BITS = 9;
+constexpr int RS_MAX_RADIX = 1 << RS_MAX_BITS;
 
-__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift,
-                                                             uint32_t digit_mask, int64_t nblocks,
-                                                             int32_t* __restrict__ block_hist) {
-  __shared__ uint32_t hist[RS_RADIX];
-  hist[threadIdx.x] = 0;
-  __syncthreads();
+// lanes (among the valid ones) whose digit equals this lane's digit
+__device__ __forceinline__ unsigned long long rs_peers(uint32_t d, bool valid) {
+  unsigned long long peers = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < RS_MAX_BITS; ++b) {
+    const bool bit = (d >> b) & 1u;
+    const unsigned long long m = __ballot(bit);
+    peers &= bit ? m : ~m;
+  }
+  return peers;
+}
+
+__device__ __forceinline__ int64_t rs_count(const int64_t* __restrict__ n_dev, int64_t n_max) {
+  if (!n_dev) return n_max;
+  const int64_t n = *n_dev;
+  return n < n_max ? n : n_max;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const uint64_t* __restrict__ keys,
+                                                             const int64_t* __restrict__ n_dev, int64_t n_max,
+                                                             int shift, uint32_t digit_mask, int64_t nb_stride,
+                                                             uint32_t* __restrict__ table) {
+  const int64_t n = rs_count(n_dev, n_max);
   const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+  if (base >= n) return;
+  __shared__ uint32_t hist[RS_MAX_RADIX];
+  hist[threadIdx.x] = 0;
+  hist[threadIdx.x + RS_THREADS] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t wbase = base + (int64_t)wave * (64 * RS_ITEMS);
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  uint64_t key[RS_ITEMS];
 #pragma unroll
   for (int i = 0; i < RS_ITEMS; ++i) {
-    const int64_t pos = base + (int64_t)i * RS_THREADS + threadIdx.x;
-    if (pos < n) {
-      const uint32_t d = (uint32_t)(keys[pos] >> shift) & digit_mask;
-      atomicAdd(&hist[d], 1u);
-    }
+    const int64_t pos = wbase + i * 64 + lane;
+    key[i] = (pos < n) ? keys[pos] : 0ull;
+  }
+#pragma unroll
+  for (int i = 0; i < RS_ITEMS; ++i) {
+    const bool valid = wbase + i * 64 + lane < n;
+    const uint32_t d = (uint32_t)(key[i] >> shift) & digit_mask;
+    const unsigned long long peers = rs_peers(d, valid);
+    if (valid && (peers & lt_mask) == 0ull) atomicAdd(&hist[d], (uint32_t)__popcll(peers));
   }
   __syncthreads();
-  block_hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = (int32_t)hist[threadIdx.x];
+  const uint32_t radix = digit_mask + 1u;
+  for (uint32_t d = threadIdx.x; d < radix; d += RS_THREADS) table[(int64_t)d * nb_stride + blockIdx.x] = hist[d];
+}
+
+// one wave per digit: exclusive scan over the active blocks of the digit's table row, total -> totals[d]
+__global__ __launch_bounds__(RS_THREADS) void rs_colscan_kernel(const int64_t* __restrict__ n_dev, int64_t n_max,
+                                                                uint32_t radix, int64_t nb_stride,
+                                                                uint32_t* __restrict__ table,
+                                                                uint32_t* __restrict__ totals) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t d = blockIdx.x * RS_WAVES + (threadIdx.x >> 6);
+  if (d >= radix) return;
+  const int64_t n = rs_count(n_dev, n_max);
+  const int64_t nb = ceil_div(n, RS_TILE);
+  uint32_t* row = table + (int64_t)d * nb_stride;
+  uint32_t run = 0;
+  for (int64_t c0 = 0; c0 < nb; c0 += 64) {
+    const int64_t c = c0 + lane;
+    const uint32_t v = (c < nb) ? row[c] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (c < nb) row[c] = run + incl - v;
+    run += __shfl(incl, 63);
+  }
+  if (lane == 0) totals[d] = run;
 }
 
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
     const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t* __restrict__ keys_out,
-    uint32_t* __restrict__ vals_out, int64_t n, int shift, uint32_t digit_mask, int64_t nblocks,
-    const int32_t* __restrict__ block_offsets) {
-  __shared__ uint32_t wave_cnt[RS_WAVES][RS_RADIX];
+    uint32_t* __restrict__ vals_out, const int64_t* __restrict__ n_dev, int64_t n_max, int shift, uint32_t digit_mask,
+    int64_t nb_stride, const uint32_t* __restrict__ table, const uint32_t* __restrict__ totals) {
+  const int64_t n = rs_count(n_dev, n_max);
+  const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+  if (base >= n) return;
+  __shared__ uint32_t wave_cnt[RS_WAVES][RS_MAX_RADIX];
+  __shared__ uint32_t dbase[RS_MAX_RADIX];
+  __shared__ uint32_t wsum[RS_WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t radix = digit_mask + 1u;
 #pragma unroll
-  for (int w = 0; w < RS_WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
-  __syncthreads();
+  for (int w = 0; w < RS_WAVES; ++w) {
+    wave_cnt[w][threadIdx.x] = 0;
+    wave_cnt[w][threadIdx.x + RS_THREADS] = 0;
+  }
+  // exclusive scan of the digit totals: thread t owns digits 2t, 2t+1
+  const uint32_t t0 = (2 * threadIdx.x < radix) ? totals[2 * threadIdx.x] : 0u;
+  const uint32_t t1 = (2 * threadIdx.x + 1 < radix) ? totals[2 * threadIdx.x + 1] : 0u;
+  {
+    uint32_t incl = t0 + t1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+#pragma unroll
+    for (int w = 0; w < RS_WAVES; ++w)
+      if (w < wave) before += wsum[w];
+    const uint32_t ex = before + incl - (t0 + t1);
+    dbase[2 * threadIdx.x] = ex;
+    dbase[2 * threadIdx.x + 1] = ex + t0;
+  }
 
-  const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)wave * (64 * RS_ITEMS);
-  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int64_t wbase = base + (int64_t)wave * (64 * RS_ITEMS);
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
   uint64_t key[RS_ITEMS];
+  uint32_t val[RS_ITEMS];
   uint32_t rank[RS_ITEMS];
 #pragma unroll
   for (int i = 0; i < RS_ITEMS; ++i) {
     const int64_t pos = wbase + i * 64 + lane;
-    key[i] = (pos < n) ? keys_in[pos] : ~0ull;
+    key[i] = (pos < n) ? keys_in[pos] : 0ull;
+    val[i] = (pos < n) ? vals_in[pos] : 0u;
   }
 #pragma unroll
   for (int i = 0; i < RS_ITEMS; ++i) {
-    const int64_t pos = wbase + i * 64 + lane;
-    const bool valid = pos < n;
+    const bool valid = wbase + i * 64 + lane < n;
     const uint32_t d = (uint32_t)(key[i] >> shift) & digit_mask;
-    unsigned long long peers = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < RS_BITS; ++b) {
-      const bool bit = (d >> b) & 1u;
-      const unsigned long long m = __ballot(bit);
-      peers &= bit ? m : ~m;
-    }
+    const unsigned long long peers = rs_peers(d, valid);
     const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
     const uint32_t prev = wave_cnt[wave][d];
     __builtin_amdgcn_wave_barrier();
@@ -76,25 +162,24 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
     rank[i] = prev + before;
   }
   __syncthreads();
-  {
-    // digit d = threadIdx.x: turn per-wave counts into per-wave global start offsets
-    uint32_t run = (uint32_t)block_offsets[(int64_t)threadIdx.x * nblocks + blockIdx.x];
+  // per-wave counts -> per-wave global start offsets
+  for (uint32_t d = threadIdx.x; d < radix; d += RS_THREADS) {
+    uint32_t run = dbase[d] + table[(int64_t)d * nb_stride + blockIdx.x];
 #pragma unroll
     for (int w = 0; w < RS_WAVES; ++w) {
-      const uint32_t c = wave_cnt[w][threadIdx.x];
-      wave_cnt[w][threadIdx.x] = run;
+      const uint32_t c = wave_cnt[w][d];
+      wave_cnt[w][d] = run;
       run += c;
     }
   }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < RS_ITEMS; ++i) {
-    const int64_t pos = wbase + i * 64 + lane;
-    if (pos < n) {
+    if (wbase + i * 64 + lane < n) {
       const uint32_t d = (uint32_t)(key[i] >> shift) & digit_mask;
       const uint32_t dst = wave_cnt[wave][d] + rank[i];
       keys_out[dst] = key[i];
-      vals_out[dst] = vals_in[pos];
+      vals_out[dst] = val[i];
     }
   }
 }
@@ -104,40 +189,43 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
 extern "C" int64_t gs_radix_sort_workspace_bytes(int64_t n) {
   if (n <= 0) return 256;
   const int64_t nb = gs::ceil_div(n, gs::RS_TILE);
-  const int64_t table = ((nb * gs::RS_RADIX * (int64_t)sizeof(int32_t) + 255) / 256) * 256;
-  return 2 * table + 256 + gs_exclusive_scan_workspace_bytes(nb * gs::RS_RADIX);
+  const int64_t table = ((nb * gs::RS_MAX_RADIX * (int64_t)sizeof(uint32_t) + 255) / 256) * 256;
+  return table + gs::RS_MAX_RADIX * (int64_t)sizeof(uint32_t);
 }
 
-extern "C" int gs_radix_sort_pairs_u64_u32(int64_t n, int32_t end_bit, uint64_t* keys_a, uint32_t* vals_a,
-                                           uint64_t* keys_b, uint32_t* vals_b, void* workspace,
-                                           int64_t workspace_bytes, int32_t* result_in_b_host, void* stream) {
-  if (n < 0 || end_bit < 0 || end_bit > 64 || !result_in_b_host) return GS_ERR_INVALID_ARG;
+extern "C" int gs_radix_sort_pairs_u64_u32_ex(int64_t n_max, const int64_t* n_dev, int32_t begin_bit, int32_t end_bit,
+                                              uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b,
+                                              void* workspace, int64_t workspace_bytes, int32_t* result_in_b_host,
+                                              void* stream) {
+  if (n_max < 0 || begin_bit < 0 || end_bit < begin_bit || end_bit > 64 || !result_in_b_host) return GS_ERR_INVALID_ARG;
   *result_in_b_host = 0;
-  if (n == 0 || end_bit == 0) return GS_OK;
-  if (n >= ((int64_t)1 << 31)) return GS_ERR_UNSUPPORTED;
+  if (n_max == 0 || end_bit == begin_bit) return GS_OK;
+  if (n_max >= ((int64_t)1 << 31)) return GS_ERR_UNSUPPORTED;
   if (!keys_a || !vals_a || !keys_b || !vals_b || !workspace) return GS_ERR_INVALID_ARG;
-  if (workspace_bytes < gs_radix_sort_workspace_bytes(n)) return GS_ERR_WORKSPACE;
+  if (workspace_bytes < gs_radix_sort_workspace_bytes(n_max)) return GS_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  const int64_t nb = gs::ceil_div(n, gs::RS_TILE);
-  const int64_t table = ((nb * gs::RS_RADIX * (int64_t)sizeof(int32_t) + 255) / 256) * 256;
-  char* ws = (char*)workspace;
-  int32_t* hist = (int32_t*)ws;
-  int32_t* offs = (int32_t*)(ws + table);
-  int64_t* total = (int64_t*)(ws + 2 * table);
-  void* scan_ws = ws + 2 * table + 256;
-  const int64_t scan_ws_bytes = workspace_bytes - (2 * table + 256);
+  const int64_t nb = gs::ceil_div(n_max, gs::RS_TILE);
+  const int64_t table_bytes = ((nb * gs::RS_MAX_RADIX * (int64_t)sizeof(uint32_t) + 255) / 256) * 256;
+  uint32_t* table = (uint32_t*)workspace;
+  uint32_t* totals = (uint32_t*)((char*)workspace + table_bytes);
+
+  const int total_bits = end_bit - begin_bit;
+  const int npass = (total_bits + gs::RS_MAX_BITS - 1) / gs::RS_MAX_BITS;
+  const int bits_per_pass = (total_bits + npass - 1) / npass;
 
   uint64_t* kin = keys_a; uint32_t* vin = vals_a;
   uint64_t* kout = keys_b; uint32_t* vout = vals_b;
   int in_b = 0;
-  for (int shift = 0; shift < end_bit; shift += gs::RS_BITS) {
-    const int nbits = (end_bit - shift < gs::RS_BITS) ? (end_bit - shift) : gs::RS_BITS;
+  for (int shift = begin_bit; shift < end_bit; shift += bits_per_pass) {
+    const int nbits = (end_bit - shift < bits_per_pass) ? (end_bit - shift) : bits_per_pass;
     const uint32_t mask = (1u << nbits) - 1u;
-    hipLaunchKernelGGL(gs::rs_hist_kernel, dim3((unsigned)nb), dim3(gs::RS_THREADS), 0, s, kin, n, shift, mask, nb, hist);
-    int st = gs_exclusive_scan_i32(hist, offs, nb * gs::RS_RADIX, total, scan_ws, scan_ws_bytes, stream);
-    if (st != GS_OK) return st;
-    hipLaunchKernelGGL(gs::rs_scatter_kernel, dim3((unsigned)nb), dim3(gs::RS_THREADS), 0, s, kin, vin, kout, vout, n,
-                       shift, mask, nb, offs);
+    const uint32_t radix = mask + 1u;
+    hipLaunchKernelGGL(gs::rs_hist_kernel, dim3((unsigned)nb), dim3(gs::RS_THREADS), 0, s, kin, n_dev, n_max, shift,
+                       mask, nb, table);
+    hipLaunchKernelGGL(gs::rs_colscan_kernel, dim3((radix + gs::RS_WAVES - 1) / gs::RS_WAVES), dim3(gs::RS_THREADS), 0,
+                       s, n_dev, n_max, radix, nb, table, totals);
+    hipLaunchKernelGGL(gs::rs_scatter_kernel, dim3((unsigned)nb), dim3(gs::RS_THREADS), 0, s, kin, vin, kout, vout,
+                       n_dev, n_max, shift, mask, nb, table, totals);
     GS_CHECK_LAUNCH();
     uint64_t* tk = kin; kin = kout; kout = tk;
     uint32_t* tv = vin; vin = vout; vout = tv;
@@ -145,4 +233,18 @@ extern "C" int gs_radix_sort_pairs_u64_u32(int64_t n, int32_t end_bit, uint64_t*
   }
   *result_in_b_host = in_b;
   return GS_OK;
+}
+
+extern "C" int gs_radix_sort_pairs_u64_u32_bits(int64_t n, int32_t begin_bit, int32_t end_bit, uint64_t* keys_a,
+                                                uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, void* workspace,
+                                                int64_t workspace_bytes, int32_t* result_in_b_host, void* stream) {
+  return gs_radix_sort_pairs_u64_u32_ex(n, nullptr, begin_bit, end_bit, keys_a, vals_a, keys_b, vals_b, workspace,
+                                        workspace_bytes, result_in_b_host, stream);
+}
+
+extern "C" int gs_radix_sort_pairs_u64_u32(int64_t n, int32_t end_bit, uint64_t* keys_a, uint32_t* vals_a,
+                                           uint64_t* keys_b, uint32_t* vals_b, void* workspace,
+                                           int64_t workspace_bytes, int32_t* result_in_b_host, void* stream) {
+  return gs_radix_sort_pairs_u64_u32_ex(n, nullptr, 0, end_bit, keys_a, vals_a, keys_b, vals_b, workspace,
+                                        workspace_bytes, result_in_b_host, stream);
 }

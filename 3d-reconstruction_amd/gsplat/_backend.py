@@ -46,7 +46,13 @@ _SIGNATURES = {
     "gs_exclusive_scan_workspace_bytes": (c_int64, [c_int64]),
     "gs_exclusive_scan_i32": (ctypes.c_int, [_P, _P, c_int64, _P, _P, c_int64, _P]),
     "gs_isect_emit": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
+    "gs_isect_count_visible": (ctypes.c_int, [_P, c_int64, _P, _P, _P, c_int64, _P]),
+    "gs_isect_depth_keys": (ctypes.c_int, [c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
+    "gs_isect_scan_ordered": (ctypes.c_int, [_P, _P, c_int64, _P, _P, _P, c_int64, _P]),
+    "gs_isect_emit_ordered": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "gs_radix_sort_workspace_bytes": (c_int64, [c_int64]),
+    "gs_radix_sort_pairs_u64_u32_ex": (ctypes.c_int, [c_int64, _P, c_int32, c_int32, _P, _P, _P, _P, _P, c_int64, POINTER(c_int32), _P]),
+    "gs_radix_sort_pairs_u64_u32_bits": (ctypes.c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, c_int64, POINTER(c_int32), _P]),
     "gs_radix_sort_pairs_u64_u32": (ctypes.c_int, [c_int64, c_int32, _P, _P, _P, _P, _P, c_int64, POINTER(c_int32), _P]),
     "gs_isect_offset_encode": (ctypes.c_int, [c_int64, _P, c_int32, c_int32, c_int32, _P, _P]),
     "gs_rasterize_fwd": (ctypes.c_int, [c_int32] * 5 + [_P, _P, _P, c_int64, _P, c_int32, _P, _P, _P, _P]),

@@ -186,8 +186,12 @@ def exclusive_scan_i32(x: Tensor) -> Tuple[Tensor, Tensor]:
     return out, total
 
 
-def radix_sort_pairs(keys: Tensor, vals: Tensor, end_bit: int) -> Tuple[Tensor, Tensor]:
-    """Stable ascending sort of (int64 key, int32 value) pairs on key bits [0, end_bit)."""
+def radix_sort_pairs(keys: Tensor, vals: Tensor, end_bit: int, begin_bit: int = 0,
+                     label: str = "gs_radix_sort_pairs_u64_u32", n_dev: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """Stable ascending sort of (int64 key, int32 value) pairs on key bits [begin_bit, end_bit).
+
+    With `n_dev` (int64 device scalar) only the first min(n_dev, len) pairs are sorted (the rest of the returned
+    buffers is undefined); the host does not need to know the count to enqueue the sort."""
     dev = B.require_gpu(keys, vals)
     assert keys.dtype == torch.int64 and vals.dtype == torch.int32 and keys.shape == vals.shape and keys.dim() == 1
     keys, vals = keys.contiguous(), vals.contiguous()
@@ -198,34 +202,78 @@ def radix_sort_pairs(keys: Tensor, vals: Tensor, end_bit: int) -> Tuple[Tensor, 
     wsb = int(B.lib().gs_radix_sort_workspace_bytes(n))
     ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
     in_b = ctypes.c_int32(0)
-    with torch.cuda.device(dev), B.timed("gs_radix_sort_pairs_u64_u32", dev):
-        B.check(B.lib().gs_radix_sort_pairs_u64_u32(n, end_bit, B.ptr(keys), B.ptr(vals), B.ptr(kb), B.ptr(vb),
-                                                    B.ptr(ws), wsb, ctypes.byref(in_b), B.stream_handle(dev)),
-                "gs_radix_sort_pairs_u64_u32")
+    with torch.cuda.device(dev), B.timed(label, dev):
+        B.check(B.lib().gs_radix_sort_pairs_u64_u32_ex(n, B.ptr(n_dev), begin_bit, end_bit, B.ptr(keys), B.ptr(vals),
+                                                       B.ptr(kb), B.ptr(vb), B.ptr(ws), wsb, ctypes.byref(in_b),
+                                                       B.stream_handle(dev)), "gs_radix_sort_pairs_u64_u32_ex")
     return (kb, vb) if in_b.value else (keys, vals)
+
+
+def _key_bits(n_cameras: int, tile_width: int, tile_height: int) -> Tuple[int, int]:
+    tile_n_bits = int(math.floor(math.log2(tile_width * tile_height))) + 1
+    cam_n_bits = int(math.floor(math.log2(n_cameras))) + 1
+    return tile_n_bits, cam_n_bits
 
 
 def isect_tiles_from_splats(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int, tile_height: int,
                             sort: bool = True) -> Tuple[Tensor, Tensor]:
-    """isect_tiles pass 2 + sort from splat records (tile boxes were computed by the projection kernel).
-    Returns (isect_ids int64 [I], flatten_ids int32 [I])."""
+    """isect_tiles pass 2 (+ sort) from splat records (tile boxes were computed by the projection kernel).
+    Returns (isect_ids int64 [I], flatten_ids int32 [I]).
+
+    sort=False: A.3's emission order (ascending flat row id c*N+n), unsorted.
+    sort=True : the result of A.3's stable sort on the (camera|tile|depth) key, produced as
+                depth pre-sort of the V visible rows -> emission in that order -> stable sort on the (camera|tile)
+                bits only; identical output, but the I-sized array is swept 2x instead of 6x."""
     dev = B.require_gpu(splats, tiles_per_gauss)
     C, N = tiles_per_gauss.shape
-    cum, total = exclusive_scan_i32(tiles_per_gauss)
-    n_isects = int(total.item())  # the one host sync of the pipeline (gsplat has the same one)
+    tile_n_bits, cam_n_bits = _key_bits(C, tile_width, tile_height)
+    if not sort:
+        cum, total = exclusive_scan_i32(tiles_per_gauss)
+        n_isects = int(total.item())
+        isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64)
+        flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
+        if n_isects:
+            with torch.cuda.device(dev), B.timed("gs_isect_emit", dev):
+                B.check(B.lib().gs_isect_emit(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
+                                              B.ptr(cum), B.ptr(isect_ids), B.ptr(flatten_ids), B.stream_handle(dev)),
+                        "gs_isect_emit")
+        return isect_ids, flatten_ids
+
+    lib, st = B.lib(), B.stream_handle(dev)
+    n = C * N
+    cum_vis = torch.empty(n, device=dev, dtype=torch.int32)
+    totals = torch.empty(2, device=dev, dtype=torch.int64)
+    wsb = int(lib.gs_exclusive_scan_workspace_bytes(n))
+    ws = torch.empty(max(wsb, 8), device=dev, dtype=torch.uint8)
+    with torch.cuda.device(dev), B.timed("gs_isect_count_visible", dev):
+        B.check(lib.gs_isect_count_visible(B.ptr(tiles_per_gauss), n, B.ptr(cum_vis), B.ptr(totals), B.ptr(ws), wsb, st),
+                "gs_isect_count_visible")
+    # everything up to the depth pre-sort is enqueued with the visible count still on the device (buffers sized for the
+    # worst case C*N), so the one host sync of the pipeline (gsplat has the same one) overlaps with that work
+    dkeys = torch.empty(n, device=dev, dtype=torch.int64)
+    order = torch.empty(n, device=dev, dtype=torch.int32)
+    with torch.cuda.device(dev), B.timed("gs_isect_depth_keys", dev):
+        B.check(lib.gs_isect_depth_keys(C, N, B.ptr(tiles_per_gauss), B.ptr(cum_vis), B.ptr(splats), B.ptr(dkeys),
+                                        B.ptr(order), st), "gs_isect_depth_keys")
+    # positive floats: bit 31 is 0, so a single camera needs 31 bits only
+    _, order = radix_sort_pairs(dkeys, order, 31 if C == 1 else 32 + cam_n_bits,
+                                label="gs_radix_sort_pairs_u64_u32[depth]", n_dev=totals[0:1])
+    n_vis, n_isects = (int(v) for v in totals.tolist())
     isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64)
     flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
     if n_isects == 0:
         return isect_ids, flatten_ids
-    with torch.cuda.device(dev), B.timed("gs_isect_emit", dev):
-        B.check(B.lib().gs_isect_emit(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
-                                      B.ptr(cum), B.ptr(isect_ids), B.ptr(flatten_ids), B.stream_handle(dev)),
-                "gs_isect_emit")
-    if sort:
-        tile_n_bits = int(math.floor(math.log2(tile_width * tile_height))) + 1
-        cam_n_bits = int(math.floor(math.log2(C))) + 1
-        isect_ids, flatten_ids = radix_sort_pairs(isect_ids, flatten_ids, 32 + tile_n_bits + cam_n_bits)
-    return isect_ids, flatten_ids
+    cum_ord = torch.empty(n_vis, device=dev, dtype=torch.int32)
+    total_ord = torch.empty(1, device=dev, dtype=torch.int64)  # == n_isects again
+    with torch.cuda.device(dev), B.timed("gs_isect_scan_ordered", dev):
+        B.check(lib.gs_isect_scan_ordered(B.ptr(tiles_per_gauss), B.ptr(order), n_vis, B.ptr(cum_ord), B.ptr(total_ord),
+                                          B.ptr(ws), wsb, st), "gs_isect_scan_ordered")
+    with torch.cuda.device(dev), B.timed("gs_isect_emit_ordered", dev):
+        B.check(lib.gs_isect_emit_ordered(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
+                                          B.ptr(order), n_vis, B.ptr(cum_ord), B.ptr(isect_ids), B.ptr(flatten_ids), st),
+                "gs_isect_emit_ordered")
+    return radix_sort_pairs(isect_ids, flatten_ids, 32 + tile_n_bits + cam_n_bits, begin_bit=32,
+                            label="gs_radix_sort_pairs_u64_u32[tile]")
 
 
 def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
