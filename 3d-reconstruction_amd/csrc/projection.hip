@@ -39,6 +39,22 @@ __device__ __forceinline__ Cam load_cam(const float* __restrict__ viewmats, cons
   return cam;
 }
 
+// Camera centre -inv(R) t of a world->camera matrix (adjugate form, so R need not be orthonormal); used for the SH
+// view directions when the caller passes no `campos` (wave-uniform: a handful of scalar ops per camera).
+__device__ __forceinline__ void cam_center(const float* __restrict__ campos, const Cam& cam, int c, float cp[3]) {
+  if (campos) {
+    cp[0] = campos[3 * c]; cp[1] = campos[3 * c + 1]; cp[2] = campos[3 * c + 2];
+    return;
+  }
+  const float* R = cam.R;
+  const float c12[3] = {R[4] * R[8] - R[5] * R[7], R[5] * R[6] - R[3] * R[8], R[3] * R[7] - R[4] * R[6]};
+  const float c20[3] = {R[7] * R[2] - R[8] * R[1], R[8] * R[0] - R[6] * R[2], R[6] * R[1] - R[7] * R[0]};
+  const float c01[3] = {R[1] * R[5] - R[2] * R[4], R[2] * R[3] - R[0] * R[5], R[0] * R[4] - R[1] * R[3]};
+  const float idet = 1.f / (R[0] * c12[0] + R[1] * c12[1] + R[2] * c12[2]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) cp[i] = -(cam.t[0] * c12[i] + cam.t[1] * c20[i] + cam.t[2] * c01[i]) * idet;
+}
+
 // wxyz (un-normalised) -> rotation matrix of the normalised quaternion; returns 1/|q| and the unit quaternion.
 __device__ __forceinline__ void quat_to_rot(const float q[4], float Rq[9], float qn[4], float& inv_norm) {
   inv_norm = rsqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
@@ -201,8 +217,9 @@ __global__ __launch_bounds__(256) void projection_fwd_kernel(
     } else if constexpr (CMODE == GS_COLOR_SH) {
       nc = 3;
       float rgb[3];
-      sh_eval<DEG>(colors + (int64_t)n * p.sh_K * 3, mu[0] - campos[3 * c], mu[1] - campos[3 * c + 1],
-                   mu[2] - campos[3 * c + 2], rgb);
+      float cp[3];
+      cam_center(campos, cam, c, cp);
+      sh_eval<DEG>(colors + (int64_t)n * p.sh_K * 3, mu[0] - cp[0], mu[1] - cp[1], mu[2] - cp[2], rgb);
 #pragma unroll
       for (int k = 0; k < 3; ++k) ch[k] = fmaxf(rgb[k] + 0.5f, 0.f);
     }
@@ -307,8 +324,10 @@ __global__ __launch_bounds__(256) void projection_bwd_kernel(
         float vrgb[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) vrgb[k] = (chv[k] > 0.f) ? vch[k] : 0.f;  // clamp_min(c+0.5, 0) gate
-        sh_eval_vjp<DEG, true>(colors + (int64_t)n * p.sh_K * 3, mu[0] - campos[3 * c], mu[1] - campos[3 * c + 1],
-                               mu[2] - campos[3 * c + 2], vrgb, v_col, vdx, vdy, vdz);
+        float cp[3];
+        cam_center(campos, cam, c, cp);
+        sh_eval_vjp<DEG, true>(colors + (int64_t)n * p.sh_K * 3, mu[0] - cp[0], mu[1] - cp[1], mu[2] - cp[2], vrgb,
+                               v_col, vdx, vdy, vdz);
         v_mu[0] += vdx; v_mu[1] += vdy; v_mu[2] += vdz;
         if constexpr (VIEWGRAD) { g_cp[0] = -vdx; g_cp[1] = -vdy; g_cp[2] = -vdz; }
       }
@@ -505,7 +524,6 @@ extern "C" int gs_projection_fwd(const gs_proj_params* p, const float* means, co
   if (!means || !quats || !scales || !opacities || !viewmats || !Ks || !radii || !means2d || !splats || !tiles_per_gauss)
     return GS_ERR_INVALID_ARG;
   if (p->color_mode != GS_COLOR_NONE && !colors) return GS_ERR_INVALID_ARG;
-  if (p->color_mode == GS_COLOR_SH && !campos) return GS_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)gs::ceil_div(p->N, 256)), block(256);
   switch (p->color_mode) {
@@ -548,7 +566,6 @@ extern "C" int gs_projection_bwd(const gs_proj_params* p, const float* means, co
       !v_splats || !v_means || !v_quats || !v_scales || !v_opacities || ld_v_means2d < 2)
     return GS_ERR_INVALID_ARG;
   if (p->color_mode != GS_COLOR_NONE && (!colors || !v_colors)) return GS_ERR_INVALID_ARG;
-  if (p->color_mode == GS_COLOR_SH && !campos) return GS_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)gs::ceil_div(p->N, 256)), block(256);
   switch (p->color_mode) {

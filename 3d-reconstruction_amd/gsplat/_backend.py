@@ -125,13 +125,29 @@ def stream_handle(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+_side_streams = {}
+
+
+def side_stream(device: torch.device) -> "torch.cuda.Stream":
+    """One auxiliary HIP stream per device for copies/fills that overlap a compute-bound kernel."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 # ---- optional per-entry-point timing with HIP events on the launch stream (used by bench.py) ----------------
 _prof = None
+_prof_only = None
 
 
-def profiling_start() -> None:
-    global _prof
+def profiling_start(only=None) -> None:
+    """Start bracketing native launches with HIP events.  `only`: iterable of entry-point labels to restrict to
+    (every bracket costs a few microseconds of stream bubble, so a timed region brackets one kernel only)."""
+    global _prof, _prof_only
     _prof = {}
+    _prof_only = set(only) if only is not None else None
 
 
 def profiling_stop():
@@ -153,7 +169,7 @@ class timed:
         self.name, self.dev, self.a = name, dev, None
 
     def __enter__(self):
-        if _prof is not None:
+        if _prof is not None and (_prof_only is None or self.name in _prof_only):
             self.a = torch.cuda.Event(enable_timing=True)
             self.a.record(torch.cuda.current_stream(self.dev))
         return self

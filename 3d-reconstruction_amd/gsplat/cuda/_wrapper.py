@@ -115,7 +115,8 @@ class _ProjectSplats(torch.autograd.Function):
         radii = torch.empty(C, N, device=dev, dtype=torch.int32)
         tiles = torch.empty(C, N, device=dev, dtype=torch.int32)
         means2d = torch.empty(C, N, 2, device=dev, dtype=torch.float32)
-        splats = torch.zeros(C, N, B.GS_REC, device=dev, dtype=torch.float32)
+        # rows with radii == 0 are never written nor read (as gsplat's torch.empty projection outputs)
+        splats = torch.empty(C, N, B.GS_REC, device=dev, dtype=torch.float32)
         with torch.cuda.device(dev), B.timed("gs_projection_fwd", dev):
             B.check(B.lib().gs_projection_fwd(
                 ctypes.byref(params), B.ptr(means), B.ptr(quats), B.ptr(scales), B.ptr(opacities), B.ptr(viewmats),
@@ -128,6 +129,7 @@ class _ProjectSplats(torch.autograd.Function):
         ctx.save_for_backward(means, quats, scales, opacities, colors if colors is not None else empty, viewmats, Ks,
                               campos if campos is not None else empty, radii, splats)
         ctx.mark_non_differentiable(radii, tiles)
+        ctx.set_materialize_grads(False)
         return splats, means2d, radii, tiles
 
     @staticmethod
@@ -304,6 +306,17 @@ class _RasterizeSplats(torch.autograd.Function):
         ra = torch.empty(C, height, width, 1, device=dev, dtype=torch.float32)
         last_ids = torch.empty(C, height, width, device=dev, dtype=torch.int32)
         n_isects = flatten_ids.numel()
+        ctx.v_splats = ctx.v_ready = None
+        if ctx.needs_input_grad[0] and n_isects > 0:
+            # the backward accumulates atomically into a zeroed gradient record; zero it now on a side stream, where
+            # the HBM-bound fill hides behind the issue-bound forward rasterizer
+            main, side = torch.cuda.current_stream(dev), B.side_stream(dev)
+            ctx.v_splats = torch.empty_like(splats)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ctx.v_splats.zero_()
+                ctx.v_ready = torch.cuda.Event()
+                ctx.v_ready.record(side)
         with torch.cuda.device(dev), B.timed("gs_rasterize_fwd", dev):
             B.check(B.lib().gs_rasterize_fwd(C, width, height, tile_size, channels, B.ptr(splats), B.ptr(offsets),
                                              B.ptr(flatten_ids), n_isects, B.ptr(bg), int(ed), B.ptr(rc), B.ptr(ra),
@@ -315,6 +328,7 @@ class _RasterizeSplats(torch.autograd.Function):
         ctx.save_for_backward(splats, means2d, offsets, flatten_ids, bg if bg is not None else empty, rc, ra, last_ids,
                               packed_index if packed_index is not None else empty)
         ctx.mark_non_differentiable(isect_ids, flatten_ids, offsets, last_ids)
+        ctx.set_materialize_grads(False)  # no zero tensors for the integer outputs' (undefined) gradients
         return rc, ra, isect_ids, flatten_ids, offsets, last_ids
 
     @staticmethod
@@ -325,7 +339,11 @@ class _RasterizeSplats(torch.autograd.Function):
         bg = bg if ctx.has_bg else None
         v_rc = B.f32c(v_rc) if v_rc is not None else torch.zeros_like(rc)
         v_ra = B.f32c(v_ra) if v_ra is not None else torch.zeros_like(ra)
-        v_splats = torch.zeros_like(splats)
+        if ctx.v_splats is not None:
+            v_splats, ctx.v_splats = ctx.v_splats, None  # single use (a second backward allocates afresh)
+            torch.cuda.current_stream(dev).wait_event(ctx.v_ready)
+        else:
+            v_splats = torch.zeros_like(splats)
         with torch.cuda.device(dev), B.timed("gs_rasterize_bwd", dev):
             B.check(B.lib().gs_rasterize_bwd(C, width, height, tile_size, channels, B.ptr(splats), B.ptr(offsets),
                                              B.ptr(flatten_ids), flatten_ids.numel(), B.ptr(bg), ed, B.ptr(rc),

@@ -100,7 +100,9 @@ def rasterization(
     elif colors.dim() == 3:
         color_mode, color_dim, col_in = B.GS_COLOR_SH, 3, colors
         sh_K = colors.shape[-2]
-        campos = W._camera_centers(viewmats)
+        # camera centres feed the SH view directions; when the poses are being optimised they stay an autograd
+        # node (v_campos -> viewmats), otherwise the kernel derives them from viewmats itself
+        campos = W._camera_centers(viewmats) if (viewmats.requires_grad and torch.is_grad_enabled()) else None
     else:
         # per-camera SH coefficients [C,N,K,3]: evaluate with the standalone op, then feed [C,N,3]
         cp = W._camera_centers(viewmats)

@@ -81,7 +81,7 @@ int gs_projection_fwd(const gs_proj_params* p,
                       const float* opacities,  /* [N]                           */
                       const float* viewmats,   /* [C,4,4] world->camera         */
                       const float* Ks,         /* [C,3,3]                       */
-                      const float* campos,     /* [C,3] camera centres (GS_COLOR_SH), else may be NULL */
+                      const float* campos,     /* [C,3] camera centres for the SH view directions; NULL: derived from viewmats in-kernel */
                       const float* colors,     /* per color_mode, may be NULL   */
                       int32_t* radii,          /* out [C,N]                     */
                       float* means2d,          /* out [C,N,2]                   */
