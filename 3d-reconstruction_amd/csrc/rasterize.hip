@@ -84,11 +84,18 @@ template <int CH>
 __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
     int C, int W, int H, int TW, int TH, const float* __restrict__ splats, const int32_t* __restrict__ offsets,
     const int32_t* __restrict__ flatten_ids, int64_t n_isects, const float* __restrict__ backgrounds, int ed,
-    float* __restrict__ out_c, float* __restrict__ out_a, int32_t* __restrict__ last_ids) {
+    float* __restrict__ out_c, float* __restrict__ out_a, int32_t* __restrict__ last_ids,
+    const int32_t* __restrict__ tile_order, int32_t* __restrict__ tile_work) {
   __shared__ float4 sg[64 * 3];
   const unsigned n_tiles = (unsigned)(C * TW * TH);
-  const unsigned tile = raster_tile_of(blockIdx.x);
-  if (tile >= n_tiles) return;
+  unsigned tile;
+  if (tile_order) {
+    if (blockIdx.x >= n_tiles) return;
+    tile = (unsigned)tile_order[blockIdx.x];
+  } else {
+    tile = raster_tile_of(blockIdx.x);
+    if (tile >= n_tiles) return;
+  }
   const TileGeom tg = tile_geom(tile, TW, TH, n_tiles, offsets, n_isects);
   const int lane = threadIdx.x;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -176,6 +183,13 @@ __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
     __syncthreads();
   }
 
+  if (tile_work) {
+    // list entries the backward will walk for this tile (it starts at the wave's largest last id)
+    int wmax = max(max(cur[0], cur[1]), max(cur[2], cur[3]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o));
+    if (lane == 0) tile_work[tile] = (tg.end > tg.start) ? max(wmax - tg.start + 1, 0) : 0;
+  }
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int x = ix0 + (p & 1), y = iy0 + (p >> 1);
@@ -252,11 +266,18 @@ __global__ __launch_bounds__(64) void rasterize_bwd_kernel(
     int C, int W, int H, int TW, int TH, const float* __restrict__ splats, const int32_t* __restrict__ offsets,
     const int32_t* __restrict__ flatten_ids, int64_t n_isects, const float* __restrict__ backgrounds, int ed,
     const float* __restrict__ out_c, const float* __restrict__ out_a, const int32_t* __restrict__ last_ids,
-    const float* __restrict__ v_out_c, const float* __restrict__ v_out_a, float* __restrict__ v_splats) {
+    const float* __restrict__ v_out_c, const float* __restrict__ v_out_a, float* __restrict__ v_splats,
+    const int32_t* __restrict__ tile_order) {
   __shared__ float4 sg[64 * 3];
   const unsigned n_tiles = (unsigned)(C * TW * TH);
-  const unsigned tile = raster_tile_of(blockIdx.x);
-  if (tile >= n_tiles) return;
+  unsigned tile;
+  if (tile_order) {
+    if (blockIdx.x >= n_tiles) return;
+    tile = (unsigned)tile_order[blockIdx.x];
+  } else {
+    tile = raster_tile_of(blockIdx.x);
+    if (tile >= n_tiles) return;
+  }
   const TileGeom tg = tile_geom(tile, TW, TH, n_tiles, offsets, n_isects);
   if (tg.end <= tg.start) return;
   const int lane = threadIdx.x;
@@ -413,6 +434,73 @@ __global__ __launch_bounds__(64) void rasterize_bwd_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------ tile schedule
+// Longest-first launch order of the tiles.  A tile is one wave; its cost is its list length (forward estimate) or the
+// number of entries the backward will actually walk (`work`, written by the forward).  Workgroups are dispatched in
+// blockIdx order as slots free up, so feeding the heavy tiles first removes the tail where a few long tiles run alone
+// on an otherwise idle chip.  Single workgroup, 1024-bucket counting sort; order inside a bucket is arbitrary (it
+// affects speed only, never a result).
+template <int ITEMS>  // register-cached costs per thread; n_tiles <= 1024 * ITEMS
+__global__ __launch_bounds__(1024) void tile_order_kernel(int n_tiles, const int32_t* __restrict__ offsets,
+                                                          int64_t n_isects, const int32_t* __restrict__ work,
+                                                          int32_t* __restrict__ order) {
+  __shared__ int red[16];
+  __shared__ unsigned hist[1024];
+  __shared__ unsigned wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int cost[ITEMS];
+  int m = 1;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int t = tid + i * 1024;
+    cost[i] = 0;
+    if (t < n_tiles) {
+      if (work) {
+        cost[i] = work[t];
+      } else {
+        const int e = (t + 1 < n_tiles) ? offsets[t + 1] : (int)n_isects;
+        cost[i] = e - offsets[t];
+      }
+    }
+    m = max(m, cost[i]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+  if (lane == 0) red[wave] = m;
+  hist[tid] = 0;
+  __syncthreads();
+  m = red[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) m = max(m, red[w]);
+  const float scale = 1023.f / (float)m;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    cost[i] = 1023 - min(1023, (int)((float)max(cost[i], 0) * scale));  // cost -> bucket, heavy first
+    if (tid + i * 1024 < n_tiles) atomicAdd(&hist[cost[i]], 1u);
+  }
+  __syncthreads();
+  const unsigned h = hist[tid];
+  unsigned incl = h;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  unsigned before = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w)
+    if (w < wave) before += wsum[w];
+  hist[tid] = before + incl - h;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int t = tid + i * 1024;
+    if (t < n_tiles) order[atomicAdd(&hist[cost[i]], 1u)] = t;
+  }
+}
+
 }  // namespace gs
 
 static int raster_check(int32_t C, int32_t width, int32_t height, int32_t tile_size, int32_t channels,
@@ -424,20 +512,21 @@ static int raster_check(int32_t C, int32_t width, int32_t height, int32_t tile_s
   return GS_OK;
 }
 
-#define GS_RF_ARGS C, width, height, TW, TH, splats, isect_offsets, flatten_ids, n_isects, backgrounds, ed_last_channel, render_colors, render_alphas, last_ids
+#define GS_RF_ARGS C, width, height, TW, TH, splats, isect_offsets, flatten_ids, n_isects, backgrounds, ed_last_channel, render_colors, render_alphas, last_ids, tile_order, tile_work
 #define GS_RF_LAUNCH(CHN) hipLaunchKernelGGL((gs::rasterize_fwd_kernel<CHN>), grid, block, 0, s, GS_RF_ARGS)
 
 extern "C" int gs_rasterize_fwd(int32_t C, int32_t width, int32_t height, int32_t tile_size, int32_t channels,
                                 const float* splats, const int32_t* isect_offsets, const int32_t* flatten_ids,
                                 int64_t n_isects, const float* backgrounds, int32_t ed_last_channel,
-                                float* render_colors, float* render_alphas, int32_t* last_ids, void* stream) {
+                                float* render_colors, float* render_alphas, int32_t* last_ids,
+                                const int32_t* tile_order, int32_t* tile_work, void* stream) {
   int st = raster_check(C, width, height, tile_size, channels, n_isects);
   if (st != GS_OK) return st;
   if (!isect_offsets || !render_colors || !render_alphas || !last_ids) return GS_ERR_INVALID_ARG;
   if (n_isects > 0 && (!splats || !flatten_ids)) return GS_ERR_INVALID_ARG;
   const int TW = (width + 15) / 16, TH = (height + 15) / 16;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(gs::raster_grid((unsigned)(C * TW * TH))), block(64);
+  dim3 grid(tile_order ? (unsigned)(C * TW * TH) : gs::raster_grid((unsigned)(C * TW * TH))), block(64);
   switch (channels) {
     case 1: GS_RF_LAUNCH(1); break;
     case 2: GS_RF_LAUNCH(2); break;
@@ -448,7 +537,7 @@ extern "C" int gs_rasterize_fwd(int32_t C, int32_t width, int32_t height, int32_
   return GS_OK;
 }
 
-#define GS_RB_ARGS C, width, height, TW, TH, splats, isect_offsets, flatten_ids, n_isects, backgrounds, ed_last_channel, render_colors, render_alphas, last_ids, v_render_colors, v_render_alphas, v_splats
+#define GS_RB_ARGS C, width, height, TW, TH, splats, isect_offsets, flatten_ids, n_isects, backgrounds, ed_last_channel, render_colors, render_alphas, last_ids, v_render_colors, v_render_alphas, v_splats, tile_order
 #define GS_RB_LAUNCH(CHN)                                                                              \
   do {                                                                                                 \
     if (absgrad)                                                                                       \
@@ -462,7 +551,7 @@ extern "C" int gs_rasterize_bwd(int32_t C, int32_t width, int32_t height, int32_
                                 int64_t n_isects, const float* backgrounds, int32_t ed_last_channel,
                                 const float* render_colors, const float* render_alphas, const int32_t* last_ids,
                                 const float* v_render_colors, const float* v_render_alphas, int32_t absgrad,
-                                float* v_splats, void* stream) {
+                                float* v_splats, const int32_t* tile_order, void* stream) {
   int st = raster_check(C, width, height, tile_size, channels, n_isects);
   if (st != GS_OK) return st;
   if (n_isects == 0) return GS_OK;
@@ -471,13 +560,30 @@ extern "C" int gs_rasterize_bwd(int32_t C, int32_t width, int32_t height, int32_
     return GS_ERR_INVALID_ARG;
   const int TW = (width + 15) / 16, TH = (height + 15) / 16;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(gs::raster_grid((unsigned)(C * TW * TH))), block(64);
+  dim3 grid(tile_order ? (unsigned)(C * TW * TH) : gs::raster_grid((unsigned)(C * TW * TH))), block(64);
   switch (channels) {
     case 1: GS_RB_LAUNCH(1); break;
     case 2: GS_RB_LAUNCH(2); break;
     case 3: GS_RB_LAUNCH(3); break;
     default: GS_RB_LAUNCH(4); break;
   }
+  GS_CHECK_LAUNCH();
+  return GS_OK;
+}
+
+extern "C" int gs_raster_tile_order(int32_t n_tiles, const int32_t* isect_offsets, int64_t n_isects,
+                                    const int32_t* tile_work, int32_t* tile_order, void* stream) {
+  if (n_tiles < 1 || n_isects < 0 || !tile_order) return GS_ERR_INVALID_ARG;
+  if (!tile_work && !isect_offsets) return GS_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (n_tiles <= 1024 * 10)
+    hipLaunchKernelGGL(gs::tile_order_kernel<10>, dim3(1), dim3(1024), 0, s, n_tiles, isect_offsets, n_isects, tile_work, tile_order);
+  else if (n_tiles <= 1024 * 32)
+    hipLaunchKernelGGL(gs::tile_order_kernel<32>, dim3(1), dim3(1024), 0, s, n_tiles, isect_offsets, n_isects, tile_work, tile_order);
+  else if (n_tiles <= 1024 * 128)
+    hipLaunchKernelGGL(gs::tile_order_kernel<128>, dim3(1), dim3(1024), 0, s, n_tiles, isect_offsets, n_isects, tile_work, tile_order);
+  else
+    return GS_ERR_UNSUPPORTED;
   GS_CHECK_LAUNCH();
   return GS_OK;
 }

@@ -317,10 +317,25 @@ class _RasterizeSplats(torch.autograd.Function):
                 ctx.v_splats.zero_()
                 ctx.v_ready = torch.cuda.Event()
                 ctx.v_ready.record(side)
+        # longest-first tile schedule: by list length now, by the walked length (written by the forward) for backward
+        n_tiles = C * TH * TW
+        order = work = None
+        if n_isects > 0 and n_tiles <= 131072:
+            order = torch.empty(n_tiles, device=dev, dtype=torch.int32)
+            work = torch.empty(n_tiles, device=dev, dtype=torch.int32) if ctx.needs_input_grad[0] else None
+            with torch.cuda.device(dev), B.timed("gs_raster_tile_order", dev):
+                B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, None, B.ptr(order),
+                                                     B.stream_handle(dev)), "gs_raster_tile_order")
         with torch.cuda.device(dev), B.timed("gs_rasterize_fwd", dev):
             B.check(B.lib().gs_rasterize_fwd(C, width, height, tile_size, channels, B.ptr(splats), B.ptr(offsets),
                                              B.ptr(flatten_ids), n_isects, B.ptr(bg), int(ed), B.ptr(rc), B.ptr(ra),
-                                             B.ptr(last_ids), B.stream_handle(dev)), "gs_rasterize_fwd")
+                                             B.ptr(last_ids), B.ptr(order), B.ptr(work), B.stream_handle(dev)),
+                    "gs_rasterize_fwd")
+        if work is not None:
+            with torch.cuda.device(dev), B.timed("gs_raster_tile_order", dev):
+                B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, B.ptr(work), B.ptr(order),
+                                                     B.stream_handle(dev)), "gs_raster_tile_order")
+        ctx.tile_order = order if work is not None else None
         ctx.geom = (C, N, width, height, tile_size, channels, int(ed), bool(absgrad))
         ctx.has_bg = bg is not None
         ctx.has_packed = packed_index is not None
@@ -348,7 +363,8 @@ class _RasterizeSplats(torch.autograd.Function):
             B.check(B.lib().gs_rasterize_bwd(C, width, height, tile_size, channels, B.ptr(splats), B.ptr(offsets),
                                              B.ptr(flatten_ids), flatten_ids.numel(), B.ptr(bg), ed, B.ptr(rc),
                                              B.ptr(ra), B.ptr(last_ids), B.ptr(v_rc), B.ptr(v_ra), int(absgrad),
-                                             B.ptr(v_splats), B.stream_handle(dev)), "gs_rasterize_bwd")
+                                             B.ptr(v_splats), B.ptr(ctx.tile_order), B.stream_handle(dev)),
+                    "gs_rasterize_bwd")
         if ctx.has_packed:
             flat = v_splats.reshape(-1, B.GS_REC)
             v_means2d = flat[packed_index, 0:2]

@@ -199,6 +199,8 @@ int gs_rasterize_fwd(int32_t C, int32_t width, int32_t height, int32_t tile_size
                      float* render_colors,        /* out [C,H,W,channels] */
                      float* render_alphas,        /* out [C,H,W]          */
                      int32_t* last_ids,           /* out [C,H,W]          */
+                     const int32_t* tile_order,   /* [C*tile_h*tile_w] launch order of the tiles (gs_raster_tile_order) or NULL */
+                     int32_t* tile_work,          /* out [C*tile_h*tile_w] list entries the backward will walk, or NULL */
                      void* stream);
 
 int gs_rasterize_bwd(int32_t C, int32_t width, int32_t height, int32_t tile_size,
@@ -212,7 +214,14 @@ int gs_rasterize_bwd(int32_t C, int32_t width, int32_t height, int32_t tile_size
                      const float* v_render_alphas,/* [C,H,W]          */
                      int32_t absgrad,
                      float* v_splats,             /* in/out [*,16], PRE-ZEROED, atomically accumulated */
+                     const int32_t* tile_order,   /* launch order of the tiles or NULL */
                      void* stream);
+
+/* Longest-first launch order of the tiles (a permutation of 0..n_tiles-1; speed only, never results): by
+ * `tile_work` when given (written by gs_rasterize_fwd), else by list length from isect_offsets. No reference
+ * counterpart: gsplat launches tiles in grid order. */
+int gs_raster_tile_order(int32_t n_tiles, const int32_t* isect_offsets, int64_t n_isects,
+                         const int32_t* tile_work, int32_t* tile_order, void* stream);
 
 /* ---- packed mode ------------------------------------------------------------------------------ */
 /* Emits, in ascending (camera, gaussian) order, the rows with radii > 0. cum_excl = exclusive scan of
