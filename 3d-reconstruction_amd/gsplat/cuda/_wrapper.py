@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -278,6 +279,41 @@ def isect_tiles_from_splats(splats: Tensor, tiles_per_gauss: Tensor, tile_width:
                             label="gs_radix_sort_pairs_u64_u32[tile]")
 
 
+def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
+                       tile_height: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """isect_tiles + sort + isect_offset_encode in one binned pipeline (include/gsplat_mi355x.h, "binned isect_tiles").
+    Returns (isect_ids int64 [I] sorted, flatten_ids int32 [I], isect_offsets int32 [C,TH,TW]), bit-identical to
+    `isect_tiles_from_splats(sort=True)` + `isect_offset_encode`."""
+    dev = B.require_gpu(splats, tiles_per_gauss)
+    C, N = tiles_per_gauss.shape
+    T = tile_width * tile_height
+    lib, st = B.lib(), B.stream_handle(dev)
+    n_slices = max(1, min(512, max(1024 // C, 1), -(-max(N, 1) // 2048)))
+    table = torch.empty(C * n_slices * T, device=dev, dtype=torch.int32)
+    counts = torch.empty(C * T, device=dev, dtype=torch.int32)
+    offsets = torch.empty(C, tile_height, tile_width, device=dev, dtype=torch.int32)
+    total = torch.empty(1, device=dev, dtype=torch.int64)
+    with torch.cuda.device(dev), B.timed("gs_isect_bin_count", dev):
+        B.check(lib.gs_isect_bin_count(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss), n_slices,
+                                       B.ptr(table), st), "gs_isect_bin_count")
+    with torch.cuda.device(dev), B.timed("gs_isect_bin_offsets", dev):
+        B.check(lib.gs_isect_bin_offsets(C, tile_width, tile_height, n_slices, B.ptr(table), B.ptr(counts),
+                                         B.ptr(offsets), B.ptr(total), st), "gs_isect_bin_offsets")
+    n_isects = int(total.item())  # the one host sync of the pipeline (gsplat has the same one)
+    isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64)
+    flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
+    if n_isects == 0:
+        return isect_ids, flatten_ids, offsets
+    pairs = torch.empty(n_isects, device=dev, dtype=torch.int64)
+    with torch.cuda.device(dev), B.timed("gs_isect_bin_scatter", dev):
+        B.check(lib.gs_isect_bin_scatter(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss), n_slices,
+                                         B.ptr(table), B.ptr(offsets), B.ptr(pairs), st), "gs_isect_bin_scatter")
+    with torch.cuda.device(dev), B.timed("gs_isect_tile_sort", dev):
+        B.check(lib.gs_isect_tile_sort(C, tile_width, tile_height, B.ptr(offsets), n_isects, B.ptr(pairs),
+                                       B.ptr(isect_ids), B.ptr(flatten_ids), st), "gs_isect_tile_sort")
+    return isect_ids, flatten_ids, offsets
+
+
 def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
     dev = B.require_gpu(isect_ids)
     offsets = torch.empty(n_cameras, tile_height, tile_width, device=dev, dtype=torch.int32)
@@ -299,8 +335,11 @@ class _RasterizeSplats(torch.autograd.Function):
         dev = B.require_gpu(splats)
         C, N = tiles_per_gauss.shape
         TW, TH = math.ceil(width / tile_size), math.ceil(height / tile_size)
-        isect_ids, flatten_ids = isect_tiles_from_splats(splats, tiles_per_gauss, TW, TH)
-        offsets = isect_offset_encode(isect_ids, C, TW, TH)
+        if TW * TH <= int(B.lib().gs_isect_bin_max_tiles()) and os.environ.get("GS_ISECT", "bin") == "bin":
+            isect_ids, flatten_ids, offsets = isect_tiles_binned(splats, tiles_per_gauss, TW, TH)
+        else:
+            isect_ids, flatten_ids = isect_tiles_from_splats(splats, tiles_per_gauss, TW, TH)
+            offsets = isect_offset_encode(isect_ids, C, TW, TH)
         bg = B.f32c(backgrounds) if backgrounds is not None else None
         rc = torch.empty(C, height, width, channels, device=dev, dtype=torch.float32)
         ra = torch.empty(C, height, width, 1, device=dev, dtype=torch.float32)

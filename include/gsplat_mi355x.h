@@ -187,6 +187,28 @@ int gs_isect_offset_encode(int64_t n_isects, const int64_t* isect_ids_sorted,
                            int32_t* offsets, /* out [C,tile_h,tile_w] */
                            void* stream);
 
+/* ---- binned isect_tiles + sort + offsets ------------------------------------------------------------------
+ * One pipeline that produces exactly what gs_isect_emit + the full-width stable sort + gs_isect_offset_encode produce
+ * (8a rows 5, 6, 7: same sorted isect_ids / flatten_ids / isect_offsets, bit for bit) without materialising or
+ * radix-sorting the unsorted key array: per-camera tile histograms over `n_slices` row slices, per-tile offsets, an
+ * LDS-cursor scatter of (depth bits, flat row id) pairs into the tile segments, and a per-tile LDS sort by depth with
+ * ties ordered by row id.  Requires tile_w * tile_h <= gs_isect_bin_max_tiles().
+ *   table        uint32 [C][n_slices][tile_h*tile_w]  scratch (count writes it, offsets turns it into slice prefixes)
+ *   tile_counts  int32  [C*tile_h*tile_w]             intersections per tile
+ *   total        int64  device scalar                 n_isects
+ *   pairs        uint64 [n_isects]                    scratch (low word depth bits, high word flat row id)      */
+int32_t gs_isect_bin_max_tiles(void);
+int gs_isect_bin_count(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, const float* splats,
+                       const int32_t* tiles_per_gauss, int32_t n_slices, uint32_t* table, void* stream);
+int gs_isect_bin_offsets(int32_t C, int32_t tile_w, int32_t tile_h, int32_t n_slices, uint32_t* table,
+                         int32_t* tile_counts, int32_t* isect_offsets, int64_t* total, void* stream);
+int gs_isect_bin_scatter(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, const float* splats,
+                         const int32_t* tiles_per_gauss, int32_t n_slices, const uint32_t* table,
+                         const int32_t* isect_offsets, uint64_t* pairs, void* stream);
+int gs_isect_tile_sort(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets, int64_t n_isects,
+                       uint64_t* pairs, int64_t* isect_ids /* out [n_isects] */, int32_t* flatten_ids /* out */,
+                       void* stream);
+
 /* ---- rasterize_to_pixels ---------------------------------------------------------------------- */
 int gs_rasterize_fwd(int32_t C, int32_t width, int32_t height, int32_t tile_size,
                      int32_t channels,            /* 1..4 colour channels of the splat record */
