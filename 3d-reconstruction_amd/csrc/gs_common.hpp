@@ -25,6 +25,10 @@ constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float ALPHA_MAX = 0.999f;
 constexpr float T_MIN = 1e-4f;
 
+// tile lists longer than this are 'long': sorted by the big-LDS class of gs_isect_tile_sort, and placed first (as a
+// block) by gs_raster_tile_order
+constexpr int TILE_LONG = 2048;
+
 __host__ __device__ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // XCD-aware, bijective remap of a linear workgroup id: workgroups b and b+8 share an XCD (observed

@@ -25,41 +25,29 @@ constexpr int BIN_COOP = 16;            // tile boxes larger than this are walke
 constexpr int BIN_MAX_TILES = 16384;    // per camera: LDS histogram of 64 KiB
 
 // ------------------------------------------------------------------------------------------ count / scatter
+// A workgroup streams its row slice 256 rows at a time.  Most rows of a camera are culled (tiles_per_gauss == 0),
+// so the visible ones are first compacted into an LDS queue {row id, tile box, depth bits} and the tile walk then
+// runs on full waves.  cnt[] is the camera's tile histogram (count) or the per-tile write cursor (scatter).
+constexpr int BIN_QCAP = 1024;
+
 template <bool SCATTER>
-__global__ __launch_bounds__(BIN_THREADS) void isect_bin_kernel(int32_t N, int32_t tile_w, int32_t T, int32_t n_slices,
-                                                                int32_t rows_per_slice,
-                                                                const float* __restrict__ splats,
-                                                                const int32_t* __restrict__ tiles_per_gauss,
-                                                                uint32_t* __restrict__ table,
-                                                                const int32_t* __restrict__ offsets,
-                                                                uint2* __restrict__ pairs) {
-  extern __shared__ uint32_t cnt[];  // [T]
-  const int c = blockIdx.y, slice = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63;
-  uint32_t* trow = table + ((int64_t)c * n_slices + slice) * T;
-  for (int t = tid; t < T; t += BIN_THREADS) cnt[t] = SCATTER ? (uint32_t)offsets[(int64_t)c * T + t] + trow[t] : 0u;
-  __syncthreads();
-  const int n0 = slice * rows_per_slice;
-  const int n1 = min(N, n0 + rows_per_slice);
-  for (int nb = n0; nb < n1; nb += BIN_THREADS) {
-    const int n = nb + tid;
+__device__ __forceinline__ void bin_drain(uint32_t* cnt, const uint4* q, int qn, int tile_w, uint2* __restrict__ pairs) {
+  const int lane = threadIdx.x & 63;
+  for (int e0 = (threadIdx.x >> 6) * 64; e0 < qn; e0 += BIN_THREADS) {
+    const int e = e0 + lane;
     int cntg = 0, x0 = 0, y0 = 0, x1 = 0;
-    uint32_t dbits = 0;
-    const int64_t idx = (int64_t)c * N + n;
-    if (n < n1) {
-      cntg = tiles_per_gauss[idx];
-      if (cntg > 0) {
-        const float4 r3 = reinterpret_cast<const float4*>(splats + idx * REC)[3];
-        const int mn = __float_as_int(r3.y), mx = __float_as_int(r3.z);
-        x0 = mn & 0xffff; y0 = mn >> 16; x1 = mx & 0xffff;
-        if (SCATTER) dbits = (uint32_t)__float_as_int(splats[idx * REC + 10]);
-      }
+    uint32_t idx = 0, dbits = 0;
+    if (e < qn) {
+      const uint4 en = q[e];
+      idx = en.x; dbits = en.w;
+      x0 = en.y & 0xffff; y0 = en.y >> 16; x1 = en.z & 0xffff;
+      cntg = (int)((en.z >> 16) - y0) * (x1 - x0);
     }
     if (cntg > 0 && cntg <= BIN_COOP) {
       int tj = x0, trow0 = y0 * tile_w;
       for (int t = 0; t < cntg; ++t) {
         const uint32_t pos = atomicAdd(&cnt[trow0 + tj], 1u);
-        if (SCATTER) pairs[pos] = make_uint2(dbits, (uint32_t)idx);
+        if (SCATTER) pairs[pos] = make_uint2(dbits, idx);
         if (++tj == x1) { tj = x0; trow0 += tile_w; }
       }
     }
@@ -69,13 +57,63 @@ __global__ __launch_bounds__(BIN_THREADS) void isect_bin_kernel(int32_t N, int32
       big &= big - 1;
       const int b_cnt = __shfl(cntg, src), b_x0 = __shfl(x0, src), b_y0 = __shfl(y0, src);
       const int b_w = __shfl(x1, src) - b_x0;
-      const uint32_t b_d = __shfl(dbits, src);
-      const uint32_t b_idx = (uint32_t)(idx - lane + src);
+      const uint32_t b_d = __shfl(dbits, src), b_idx = __shfl(idx, src);
       for (int t = lane; t < b_cnt; t += 64) {
         const int ti = b_y0 + t / b_w, tj = b_x0 + t % b_w;
         const uint32_t pos = atomicAdd(&cnt[ti * tile_w + tj], 1u);
         if (SCATTER) pairs[pos] = make_uint2(b_d, b_idx);
       }
+    }
+  }
+}
+
+template <bool SCATTER>
+__global__ __launch_bounds__(BIN_THREADS) void isect_bin_kernel(int32_t N, int32_t tile_w, int32_t T, int32_t n_slices,
+                                                                int32_t rows_per_slice,
+                                                                const float* __restrict__ splats,
+                                                                const int32_t* __restrict__ tiles_per_gauss,
+                                                                uint32_t* __restrict__ table,
+                                                                const int32_t* __restrict__ offsets,
+                                                                uint2* __restrict__ pairs) {
+  extern __shared__ uint32_t cnt[];  // [T]
+  __shared__ uint4 q[BIN_QCAP];
+  __shared__ int q_n;
+  const int c = blockIdx.y, slice = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  uint32_t* trow = table + ((int64_t)c * n_slices + slice) * T;
+  for (int t = tid; t < T; t += BIN_THREADS) cnt[t] = SCATTER ? (uint32_t)offsets[(int64_t)c * T + t] + trow[t] : 0u;
+  if (tid == 0) q_n = 0;
+  __syncthreads();
+  const int n0 = slice * rows_per_slice;
+  const int n1 = min(N, n0 + rows_per_slice);
+  int cntg = (n0 + tid < n1) ? tiles_per_gauss[(int64_t)c * N + n0 + tid] : 0;
+  for (int nb = n0; nb < n1; nb += BIN_THREADS) {
+    const int64_t idx = (int64_t)c * N + nb + tid;
+    const bool vis = cntg > 0;
+    // next block's counts are in flight while this one is queued
+    const int nn = nb + BIN_THREADS + tid;
+    const int cnt_next = (nn < n1) ? tiles_per_gauss[(int64_t)c * N + nn] : 0;
+    const unsigned long long vm = __ballot(vis);
+    int qbase = 0;
+    if (lane == 0 && vm) qbase = atomicAdd(&q_n, __popcll(vm));
+    qbase = __shfl(qbase, 0);
+    if (vis) {
+      const float4 r3 = reinterpret_cast<const float4*>(splats + idx * REC)[3];
+      const uint32_t dbits = SCATTER ? (uint32_t)__float_as_int(splats[idx * REC + 10]) : 0u;
+      q[qbase + __popcll(vm & lt_mask)] =
+          make_uint4((uint32_t)idx, (uint32_t)__float_as_int(r3.y), (uint32_t)__float_as_int(r3.z), dbits);
+    }
+    cntg = cnt_next;
+    // a block appends at most 256 entries, so draining every QCAP/256 blocks (a data-independent, workgroup-uniform
+    // decision) can never overflow the queue
+    const int it = (nb - n0) / BIN_THREADS;
+    if ((it % (BIN_QCAP / BIN_THREADS)) == (BIN_QCAP / BIN_THREADS) - 1 || nb + BIN_THREADS >= n1) {
+      __syncthreads();
+      bin_drain<SCATTER>(cnt, q, q_n, tile_w, pairs);
+      __syncthreads();
+      if (tid == 0) q_n = 0;
+      __syncthreads();
     }
   }
   if (!SCATTER) {
@@ -156,15 +194,14 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(int64_t n_tiles, cons
 }
 
 // ------------------------------------------------------------------------------------------ per-tile sort
-constexpr int TS_THREADS = 256;
-constexpr int TS_WAVES = 4;
-constexpr int TS_CAP = 2048;  // segment entries sorted in LDS; longer segments use global scratch
+constexpr int TS_MAX_BITS = 9;
+constexpr int TS_MAX_RADIX = 1 << TS_MAX_BITS;
 
-// lanes (among the valid ones) holding the same 8-bit digit
+// lanes (among the valid ones) holding the same digit (up to 9 bits)
 __device__ __forceinline__ unsigned long long ts_peers(uint32_t d, bool valid) {
   unsigned long long peers = __ballot(valid);
 #pragma unroll
-  for (int b = 0; b < 8; ++b) {
+  for (int b = 0; b < TS_MAX_BITS; ++b) {
     const bool bit = (d >> b) & 1u;
     const unsigned long long m = __ballot(bit);
     peers &= bit ? m : ~m;
@@ -172,81 +209,142 @@ __device__ __forceinline__ unsigned long long ts_peers(uint32_t d, bool valid) {
   return peers;
 }
 
-// One stable counting pass on digit (key >> shift) & 255 from `in` to `out` (n entries, whole workgroup).
-// Returns false (and moves nothing) when every key has the same digit.
-template <typename RankT>
-__device__ __forceinline__ bool ts_pass(const uint2* in, uint2* out, RankT* ranks, int n, int shift,
-                                        uint32_t (*wave_cnt)[256], uint32_t* wsum, int* flag) {
+template <int WAVES>
+struct TsShared {
+  uint32_t wave_cnt[WAVES][TS_MAX_RADIX];
+  uint32_t wsum[4];
+  uint32_t red_min[WAVES], red_max[WAVES];
+};
+
+// One stable counting pass on digit (key >> shift) & mask from `in` to `out` (n entries, whole workgroup of WAVES
+// waves; every wave ranks a contiguous chunk, so wave order = input order).
+template <int WAVES, typename RankT>
+__device__ __forceinline__ void ts_pass(const uint2* in, uint2* out, RankT* ranks, int n, int shift, uint32_t mask,
+                                        TsShared<WAVES>& sh) {
+  constexpr int THREADS = WAVES * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
-  const int chunk = ((n + TS_WAVES * 64 - 1) / (TS_WAVES * 64)) * 64;  // per-wave contiguous chunk, multiple of 64
+  const int chunk = ((n + THREADS - 1) / THREADS) * 64;  // per-wave contiguous chunk, multiple of 64
   const int cb = wave * chunk, ce = min(n, cb + chunk);
-#pragma unroll
-  for (int w = 0; w < TS_WAVES; ++w) wave_cnt[w][tid] = 0;
-  if (tid == 0) *flag = 0;
+  for (int i = tid; i < WAVES * TS_MAX_RADIX; i += THREADS) (&sh.wave_cnt[0][0])[i] = 0;
   __syncthreads();
-  for (int b = cb; b < ce; b += 64) {
-    const int i = b + lane;
-    const bool valid = i < ce;
-    const uint32_t d = valid ? ((in[i].x >> shift) & 255u) : 0u;
-    const unsigned long long peers = ts_peers(d, valid);
-    const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
-    const uint32_t prev = wave_cnt[wave][d];
-    __builtin_amdgcn_wave_barrier();
-    if (valid && before == 0) wave_cnt[wave][d] = prev + (uint32_t)__popcll(peers);
-    __builtin_amdgcn_wave_barrier();
-    if (valid) ranks[i] = (RankT)(prev + before);
+  // U items per lane per trip: the U peer masks (nine ballots each) are independent instruction streams; only the
+  // running-count update below is serial
+  constexpr int U = 1;
+  for (int b = cb; b < ce; b += 64 * U) {
+    uint32_t d[U], before[U], npeer[U];
+    bool valid[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = b + u * 64 + lane;
+      valid[u] = i < ce;
+      d[u] = valid[u] ? ((in[i].x >> shift) & mask) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned long long peers = ts_peers(d[u], valid[u]);
+      before[u] = (uint32_t)__popcll(peers & lt_mask);
+      npeer[u] = (uint32_t)__popcll(peers);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t prev = sh.wave_cnt[wave][d[u]];
+      __builtin_amdgcn_wave_barrier();
+      if (valid[u] && before[u] == 0) sh.wave_cnt[wave][d[u]] = prev + npeer[u];
+      __builtin_amdgcn_wave_barrier();
+      if (valid[u]) ranks[b + u * 64 + lane] = (RankT)(prev + before[u]);
+    }
   }
   __syncthreads();
-  {
-    // thread d: digit total, exclusive scan over the digits, then per-wave start offsets
-    uint32_t tot = 0;
+  // the first min(THREADS, 256) threads own DPT consecutive digits each: totals, exclusive scan over the digits,
+  // then per-wave start offsets
+  constexpr int SCAN_T = THREADS < 256 ? THREADS : 256;
+  constexpr int DPT = TS_MAX_RADIX / SCAN_T;
+  uint32_t tot[DPT], sum = 0, incl = 0;
+  if (tid < SCAN_T) {
 #pragma unroll
-    for (int w = 0; w < TS_WAVES; ++w) tot += wave_cnt[w][tid];
-    if (tot == (uint32_t)n) *flag = 1;
-    uint32_t incl = tot;
+    for (int j = 0; j < DPT; ++j) {
+      tot[j] = 0;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) tot[j] += sh.wave_cnt[w][DPT * tid + j];
+      sum += tot[j];
+    }
+    incl = sum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const uint32_t t = __shfl_up(incl, o);
       if (lane >= o) incl += t;
     }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t run = incl - tot;
+    if (lane == 63) sh.wsum[wave] = incl;
+  }
+  __syncthreads();
+  if (tid < SCAN_T) {
+    uint32_t run = incl - sum;
 #pragma unroll
-    for (int w = 0; w < TS_WAVES; ++w)
-      if (w < wave) run += wsum[w];
+    for (int w = 0; w < SCAN_T / 64; ++w)
+      if (w < wave) run += sh.wsum[w];
 #pragma unroll
-    for (int w = 0; w < TS_WAVES; ++w) {
-      const uint32_t c = wave_cnt[w][tid];
-      wave_cnt[w][tid] = run;
-      run += c;
+    for (int j = 0; j < DPT; ++j) {
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) {
+        const uint32_t c = sh.wave_cnt[w][DPT * tid + j];
+        sh.wave_cnt[w][DPT * tid + j] = run;
+        run += c;
+      }
     }
   }
   __syncthreads();
-  if (*flag) return false;
-  for (int b = cb; b < ce; b += 64) {
-    const int i = b + lane;
-    if (i < ce) {
-      const uint2 e = in[i];
-      out[wave_cnt[wave][(e.x >> shift) & 255u] + (uint32_t)ranks[i]] = e;
+  for (int b = cb; b < ce; b += 64 * U) {
+    uint2 e[U];
+    uint32_t dst[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = b + u * 64 + lane;
+      if (i < ce) {
+        e[u] = in[i];
+        dst[u] = sh.wave_cnt[wave][(e[u].x >> shift) & mask] + (uint32_t)ranks[i];
+      }
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (b + u * 64 + lane < ce) out[dst[u]] = e[u];
   }
   __syncthreads();
-  return true;
 }
 
-template <typename RankT>
-__device__ __forceinline__ uint2* ts_sort(uint2* a, uint2* b, RankT* ranks, int n, uint32_t (*wave_cnt)[256],
-                                          uint32_t* wsum, int* flag) {
+// Sorts n (depth bits, row id) pairs held in `a` (scratch `b`); returns the buffer that holds the result.
+// Only the key bits that differ inside the segment are sorted (a tile's depths share their high bits), in the
+// fewest passes of at most 9 bits.
+template <int WAVES, typename RankT>
+__device__ __forceinline__ uint2* ts_sort(uint2* a, uint2* b, RankT* ranks, int n, TsShared<WAVES>& sh) {
+  constexpr int THREADS = WAVES * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t kmin = 0xffffffffu, kmax = 0u;
+  for (int i = tid; i < n; i += THREADS) {
+    const uint32_t k = a[i].x;
+    kmin = min(kmin, k);
+    kmax = max(kmax, k);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o));
+    kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o));
+  }
+  if (lane == 0) { sh.red_min[wave] = kmin; sh.red_max[wave] = kmax; }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w) { kmin = min(kmin, sh.red_min[w]); kmax = max(kmax, sh.red_max[w]); }
+  const uint32_t diff = kmin ^ kmax;
+  const int nbits = diff ? 32 - __clz((int)diff) : 0;
+  const int npass = (nbits + TS_MAX_BITS - 1) / TS_MAX_BITS;
+  const int bpp = npass ? (nbits + npass - 1) / npass : 0;
   uint2* cur = a;
   uint2* oth = b;
 #pragma unroll 1
-  for (int shift = 0; shift < 32; shift += 8) {
-    if (ts_pass<RankT>(cur, oth, ranks, n, shift, wave_cnt, wsum, flag)) {
-      uint2* t = cur; cur = oth; oth = t;
-    }
-    __syncthreads();
+  for (int shift = 0; shift < nbits; shift += bpp) {
+    const int nb = min(bpp, nbits - shift);
+    ts_pass<WAVES, RankT>(cur, oth, ranks, n, shift, (1u << nb) - 1u, sh);
+    uint2* t = cur; cur = oth; oth = t;
   }
   // equal depths must come out in ascending row id (A.3: stable sort of an id-ordered emission): odd-even
   // transposition restricted to equal keys, until a full round moves nothing (one round when there are no ties)
@@ -254,7 +352,7 @@ __device__ __forceinline__ uint2* ts_sort(uint2* a, uint2* b, RankT* ranks, int 
     int moved = 0;
 #pragma unroll 1
     for (int phase = 0; phase < 2; ++phase) {
-      for (int i = 2 * threadIdx.x + phase; i + 1 < n; i += 2 * TS_THREADS) {
+      for (int i = 2 * tid + phase; i + 1 < n; i += 2 * THREADS) {
         const uint2 lo = cur[i], hi = cur[i + 1];
         if (lo.x == hi.x && lo.y > hi.y) {
           cur[i] = hi;
@@ -269,44 +367,59 @@ __device__ __forceinline__ uint2* ts_sort(uint2* a, uint2* b, RankT* ranks, int 
   return cur;
 }
 
-__global__ __launch_bounds__(TS_THREADS) void tile_sort_kernel(int32_t T, int32_t tile_n_bits, int64_t n_tiles,
+// CLS < 0: every tile in grid order, one workgroup each; segments up to CAP in LDS, longer ones on global scratch.
+// CLS 0..3: size class CLS of the longest-first order (tile_order, size_classes from gs_raster_tile_order):
+//   class 0 = tile_order[0 .. sc[0])  lists > 2048    class 1 = [sc[0] .. sc[1])  1025..2048
+//   class 2 = [sc[1] .. sc[2])        513..1024       class 3 = [sc[2] .. n_tiles)  <= 512
+// A persistent grid strides over the class.  Class 0 sorts up to CAP in LDS and anything longer on global scratch.
+template <int CAP, int CLS, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(int32_t T, int32_t tile_n_bits, int64_t n_tiles,
                                                                const int32_t* __restrict__ offsets, int64_t n_isects,
-                                                               uint2* pairs, int64_t* isect_ids, int32_t* flatten_ids) {
-  __shared__ uint2 buf_a[TS_CAP];
-  __shared__ uint2 buf_b[TS_CAP];
-  __shared__ uint16_t rank_s[TS_CAP];
-  __shared__ uint32_t wave_cnt[TS_WAVES][256];
-  __shared__ uint32_t wsum[TS_WAVES];
-  __shared__ int flag;
-  const int64_t tile = blockIdx.x;
-  const int start = offsets[tile];
-  const int end = (tile + 1 < n_tiles) ? offsets[tile + 1] : (int)n_isects;
-  const int n = end - start;
-  if (n <= 0) return;
-  const int64_t cam = tile / T, tl = tile - cam * T;
-  const int64_t key_hi = (cam << (32 + tile_n_bits)) | (tl << 32);
-  if (n <= TS_CAP) {
-    for (int i = threadIdx.x; i < n; i += TS_THREADS) buf_a[i] = pairs[start + i];
+                                                               const int32_t* __restrict__ tile_order,
+                                                               const int32_t* __restrict__ size_classes, uint2* pairs,
+                                                               int64_t* isect_ids, int32_t* flatten_ids) {
+  constexpr int THREADS = WAVES * 64;
+  __shared__ uint2 buf_a[CAP];
+  __shared__ uint2 buf_b[CAP];
+  __shared__ uint16_t rank_s[CAP];
+  __shared__ TsShared<WAVES> sh;
+  int64_t k = blockIdx.x, k_end = n_tiles;
+  if (CLS >= 0) {
+    k += (CLS > 0) ? size_classes[CLS - 1] : 0;
+    k_end = (CLS < 3) ? size_classes[CLS] : n_tiles;
+  }
+  for (; k < k_end; k += gridDim.x) {
+    const int64_t tile = (CLS < 0) ? k : (int64_t)tile_order[k];
+    const int start = offsets[tile];
+    const int end = (tile + 1 < n_tiles) ? offsets[tile + 1] : (int)n_isects;
+    const int n = end - start;
+    if (n <= 0) continue;
+    const int64_t cam = tile / T, tl = tile - cam * T;
+    const int64_t key_hi = (cam << (32 + tile_n_bits)) | (tl << 32);
+    if (n <= CAP) {
+      for (int i = threadIdx.x; i < n; i += THREADS) buf_a[i] = pairs[start + i];
+      __syncthreads();
+      const uint2* cur = ts_sort<WAVES, uint16_t>(buf_a, buf_b, rank_s, n, sh);
+      for (int i = threadIdx.x; i < n; i += THREADS) {
+        const uint2 e = cur[i];
+        isect_ids[start + i] = key_hi | (int64_t)e.x;
+        flatten_ids[start + i] = (int32_t)e.y;
+      }
+    } else if (CLS <= 0) {
+      // very long segment: same algorithm on global scratch -- the pair array, the (not yet written) isect_ids segment
+      // as the second pair buffer, the flatten_ids segment as the rank array.  One workgroup owns the whole segment.
+      uint2* ga = pairs + start;
+      uint2* gb = reinterpret_cast<uint2*>(isect_ids + start);
+      uint32_t* gr = reinterpret_cast<uint32_t*>(flatten_ids + start);
+      const uint2* cur = ts_sort<WAVES, uint32_t>(ga, gb, gr, n, sh);
+      // every thread converts its own entries; entry i of either buffer maps onto output slot i
+      for (int i = threadIdx.x; i < n; i += THREADS) {
+        const uint2 e = cur[i];
+        isect_ids[start + i] = key_hi | (int64_t)e.x;
+        flatten_ids[start + i] = (int32_t)e.y;
+      }
+    }
     __syncthreads();
-    const uint2* cur = ts_sort<uint16_t>(buf_a, buf_b, rank_s, n, wave_cnt, wsum, &flag);
-    for (int i = threadIdx.x; i < n; i += TS_THREADS) {
-      const uint2 e = cur[i];
-      isect_ids[start + i] = key_hi | (int64_t)e.x;
-      flatten_ids[start + i] = (int32_t)e.y;
-    }
-  } else {
-    // long segment: same algorithm on global scratch -- the pair array, the (not yet written) isect_ids segment as the
-    // second pair buffer, the flatten_ids segment as the rank array.  One workgroup owns the whole segment.
-    uint2* ga = pairs + start;
-    uint2* gb = reinterpret_cast<uint2*>(isect_ids + start);
-    uint32_t* gr = reinterpret_cast<uint32_t*>(flatten_ids + start);
-    const uint2* cur = ts_sort<uint32_t>(ga, gb, gr, n, wave_cnt, wsum, &flag);
-    // every thread converts its own entries; entry i of either buffer maps onto output slot i
-    for (int i = threadIdx.x; i < n; i += TS_THREADS) {
-      const uint2 e = cur[i];
-      isect_ids[start + i] = key_hi | (int64_t)e.x;
-      flatten_ids[start + i] = (int32_t)e.y;
-    }
   }
 }
 
@@ -375,8 +488,8 @@ extern "C" int gs_isect_bin_scatter(int32_t C, int32_t N, int32_t tile_w, int32_
 }
 
 extern "C" int gs_isect_tile_sort(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets,
-                                  int64_t n_isects, uint64_t* pairs, int64_t* isect_ids, int32_t* flatten_ids,
-                                  void* stream) {
+                                  int64_t n_isects, const int32_t* tile_order, const int32_t* size_classes, uint64_t* pairs,
+                                  int64_t* isect_ids, int32_t* flatten_ids, void* stream) {
   if (C < 1 || tile_w < 1 || tile_h < 1 || n_isects < 0) return GS_ERR_INVALID_ARG;
   if (n_isects == 0) return GS_OK;
   if (n_isects >= ((int64_t)1 << 31)) return GS_ERR_UNSUPPORTED;
@@ -386,9 +499,19 @@ extern "C" int gs_isect_tile_sort(int32_t C, int32_t tile_w, int32_t tile_h, con
   const int cam_n_bits = gs::bin_ilog2_floor(C) + 1;
   if (32 + tile_n_bits + cam_n_bits > 64) return GS_ERR_UNSUPPORTED;
   const int64_t n_tiles = (int64_t)C * T;
-  hipLaunchKernelGGL(gs::tile_sort_kernel, dim3((unsigned)n_tiles), dim3(gs::TS_THREADS), 0, (hipStream_t)stream, T,
-                     tile_n_bits, n_tiles, isect_offsets, n_isects, reinterpret_cast<uint2*>(pairs), isect_ids,
-                     flatten_ids);
+  hipStream_t s = (hipStream_t)stream;
+  uint2* pr = reinterpret_cast<uint2*>(pairs);
+#define GS_TS_ARGS T, tile_n_bits, n_tiles, isect_offsets, n_isects, tile_order, size_classes, pr, isect_ids, flatten_ids
+  if (tile_order && size_classes) {
+    // longest lists first; grids are persistent and sized to the LDS-limited residency of each class
+    hipLaunchKernelGGL((gs::tile_sort_kernel<6144, 0, 16>), dim3(256), dim3(1024), 0, s, GS_TS_ARGS);
+    hipLaunchKernelGGL((gs::tile_sort_kernel<2048, 1, 4>), dim3(256 * 3), dim3(256), 0, s, GS_TS_ARGS);
+    hipLaunchKernelGGL((gs::tile_sort_kernel<1024, 2, 1>), dim3(256 * 8), dim3(64), 0, s, GS_TS_ARGS);
+    hipLaunchKernelGGL((gs::tile_sort_kernel<512, 3, 1>), dim3(256 * 14), dim3(64), 0, s, GS_TS_ARGS);
+  } else {
+    hipLaunchKernelGGL((gs::tile_sort_kernel<2048, -1, 4>), dim3((unsigned)n_tiles), dim3(256), 0, s, GS_TS_ARGS);
+  }
+#undef GS_TS_ARGS
   GS_CHECK_LAUNCH();
   return GS_OK;
 }

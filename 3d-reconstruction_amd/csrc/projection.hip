@@ -248,7 +248,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 template <int CMODE, int DEG, bool VIEWGRAD>
-__global__ __launch_bounds__(256) void projection_bwd_kernel(
+__global__ __launch_bounds__(256, 2) void projection_bwd_kernel(
     gs_proj_params p, const float* __restrict__ means, const float* __restrict__ quats,
     const float* __restrict__ scales, const float* __restrict__ opacities, const float* __restrict__ viewmats,
     const float* __restrict__ Ks, const float* __restrict__ campos, const float* __restrict__ colors,

@@ -443,7 +443,7 @@ __global__ __launch_bounds__(64) void rasterize_bwd_kernel(
 template <int ITEMS>  // register-cached costs per thread; n_tiles <= 1024 * ITEMS
 __global__ __launch_bounds__(1024) void tile_order_kernel(int n_tiles, const int32_t* __restrict__ offsets,
                                                           int64_t n_isects, const int32_t* __restrict__ work,
-                                                          int32_t* __restrict__ order) {
+                                                          int32_t* __restrict__ order, int32_t* __restrict__ n_long) {
   __shared__ int red[16];
   __shared__ unsigned hist[1024];
   __shared__ unsigned wsum[16];
@@ -472,10 +472,16 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int n_tiles, const int
   m = red[0];
 #pragma unroll
   for (int w = 1; w < 16; ++w) m = max(m, red[w]);
-  const float scale = 1023.f / (float)m;
+  // cost -> bucket, heavy first.  Buckets 0..255 hold exactly the costs above TILE_LONG (= 2048); below that the
+  // bucket is 1023 - 3(c-1)/8, whose edges fall on c = 1024 | 1025 (bucket 640 | 639) and c = 512 | 513 (832 | 831),
+  // so the size classes of gs_isect_tile_sort are contiguous ranges of the order
+  static_assert(TILE_LONG == 2048, "bucket edges below assume 2048");
+  const float scale_hi = 255.f / (float)max(m - TILE_LONG, 1);
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
-    cost[i] = 1023 - min(1023, (int)((float)max(cost[i], 0) * scale));  // cost -> bucket, heavy first
+    const int c = max(cost[i], 0);
+    cost[i] = (c > TILE_LONG) ? 255 - min(255, (int)((float)(c - TILE_LONG) * scale_hi))
+                              : 1023 - ((3 * max(c - 1, 0)) >> 3);
     if (tid + i * 1024 < n_tiles) atomicAdd(&hist[cost[i]], 1u);
   }
   __syncthreads();
@@ -493,6 +499,11 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int n_tiles, const int
   for (int w = 0; w < 16; ++w)
     if (w < wave) before += wsum[w];
   hist[tid] = before + incl - h;
+  if (n_long) {  // size_classes[3]: tiles with cost > 2048, > 1024, > 512 (= tiles in the buckets before 256, 640, 832)
+    if (tid == 256) n_long[0] = (int32_t)(before + incl - h);
+    if (tid == 640) n_long[1] = (int32_t)(before + incl - h);
+    if (tid == 832) n_long[2] = (int32_t)(before + incl - h);
+  }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
@@ -572,16 +583,16 @@ extern "C" int gs_rasterize_bwd(int32_t C, int32_t width, int32_t height, int32_
 }
 
 extern "C" int gs_raster_tile_order(int32_t n_tiles, const int32_t* isect_offsets, int64_t n_isects,
-                                    const int32_t* tile_work, int32_t* tile_order, void* stream) {
+                                    const int32_t* tile_work, int32_t* tile_order, int32_t* n_long, void* stream) {
   if (n_tiles < 1 || n_isects < 0 || !tile_order) return GS_ERR_INVALID_ARG;
   if (!tile_work && !isect_offsets) return GS_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
   if (n_tiles <= 1024 * 10)
-    hipLaunchKernelGGL(gs::tile_order_kernel<10>, dim3(1), dim3(1024), 0, s, n_tiles, isect_offsets, n_isects, tile_work, tile_order);
+    hipLaunchKernelGGL(gs::tile_order_kernel<10>, dim3(1), dim3(1024), 0, s, n_tiles, isect_offsets, n_isects, tile_work, tile_order, n_long);
   else if (n_tiles <= 1024 * 32)
-    hipLaunchKernelGGL(gs::tile_order_kernel<32>, dim3(1), dim3(1024), 0, s, n_tiles, isect_offsets, n_isects, tile_work, tile_order);
+    hipLaunchKernelGGL(gs::tile_order_kernel<32>, dim3(1), dim3(1024), 0, s, n_tiles, isect_offsets, n_isects, tile_work, tile_order, n_long);
   else if (n_tiles <= 1024 * 128)
-    hipLaunchKernelGGL(gs::tile_order_kernel<128>, dim3(1), dim3(1024), 0, s, n_tiles, isect_offsets, n_isects, tile_work, tile_order);
+    hipLaunchKernelGGL(gs::tile_order_kernel<128>, dim3(1), dim3(1024), 0, s, n_tiles, isect_offsets, n_isects, tile_work, tile_order, n_long);
   else
     return GS_ERR_UNSUPPORTED;
   GS_CHECK_LAUNCH();

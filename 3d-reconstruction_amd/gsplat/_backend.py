@@ -54,7 +54,7 @@ _SIGNATURES = {
     "gs_isect_bin_count": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, c_int32, _P, _P]),
     "gs_isect_bin_offsets": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P]),
     "gs_isect_bin_scatter": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, c_int32, _P, _P, _P, _P]),
-    "gs_isect_tile_sort": (ctypes.c_int, [c_int32, c_int32, c_int32, _P, c_int64, _P, _P, _P, _P]),
+    "gs_isect_tile_sort": (ctypes.c_int, [c_int32, c_int32, c_int32, _P, c_int64, _P, _P, _P, _P, _P, _P]),
     "gs_radix_sort_workspace_bytes": (c_int64, [c_int64]),
     "gs_radix_sort_pairs_u64_u32_ex": (ctypes.c_int, [c_int64, _P, c_int32, c_int32, _P, _P, _P, _P, _P, c_int64, POINTER(c_int32), _P]),
     "gs_radix_sort_pairs_u64_u32_bits": (ctypes.c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, c_int64, POINTER(c_int32), _P]),
@@ -62,7 +62,7 @@ _SIGNATURES = {
     "gs_isect_offset_encode": (ctypes.c_int, [c_int64, _P, c_int32, c_int32, c_int32, _P, _P]),
     "gs_rasterize_fwd": (ctypes.c_int, [c_int32] * 5 + [_P, _P, _P, c_int64, _P, c_int32, _P, _P, _P, _P, _P, _P]),
     "gs_rasterize_bwd": (ctypes.c_int, [c_int32] * 5 + [_P, _P, _P, c_int64, _P, c_int32, _P, _P, _P, _P, _P, c_int32, _P, _P, _P]),
-    "gs_raster_tile_order": (ctypes.c_int, [c_int32, _P, c_int64, _P, _P, _P]),
+    "gs_raster_tile_order": (ctypes.c_int, [c_int32, _P, c_int64, _P, _P, _P, _P]),
     "gs_mark_visible": (ctypes.c_int, [c_int64, _P, _P, _P]),
     "gs_compact_visible": (ctypes.c_int, [c_int32, c_int32] + [_P] * 10 + [_P]),
 }

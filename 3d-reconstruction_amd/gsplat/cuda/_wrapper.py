@@ -280,15 +280,17 @@ def isect_tiles_from_splats(splats: Tensor, tiles_per_gauss: Tensor, tile_width:
 
 
 def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
-                       tile_height: int) -> Tuple[Tensor, Tensor, Tensor]:
+                       tile_height: int) -> Tuple[Tensor, Tensor, Tensor, Optional[Tensor]]:
     """isect_tiles + sort + isect_offset_encode in one binned pipeline (include/gsplat_mi355x.h, "binned isect_tiles").
-    Returns (isect_ids int64 [I] sorted, flatten_ids int32 [I], isect_offsets int32 [C,TH,TW]), bit-identical to
-    `isect_tiles_from_splats(sort=True)` + `isect_offset_encode`."""
+    Returns (isect_ids int64 [I] sorted, flatten_ids int32 [I], isect_offsets int32 [C,TH,TW], tile_order), the first
+    three bit-identical to `isect_tiles_from_splats(sort=True)` + `isect_offset_encode`; tile_order is the
+    longest-list-first tile permutation (int32 [C*TH*TW], or None) that the per-tile kernels are launched in."""
     dev = B.require_gpu(splats, tiles_per_gauss)
     C, N = tiles_per_gauss.shape
     T = tile_width * tile_height
     lib, st = B.lib(), B.stream_handle(dev)
     n_slices = max(1, min(512, max(1024 // C, 1), -(-max(N, 1) // 2048)))
+    n_slices = int(os.environ.get('GS_SLICES', n_slices))
     table = torch.empty(C * n_slices * T, device=dev, dtype=torch.int32)
     counts = torch.empty(C * T, device=dev, dtype=torch.int32)
     offsets = torch.empty(C, tile_height, tile_width, device=dev, dtype=torch.int32)
@@ -299,19 +301,26 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
     with torch.cuda.device(dev), B.timed("gs_isect_bin_offsets", dev):
         B.check(lib.gs_isect_bin_offsets(C, tile_width, tile_height, n_slices, B.ptr(table), B.ptr(counts),
                                          B.ptr(offsets), B.ptr(total), st), "gs_isect_bin_offsets")
+    order = n_long = None
+    if C * T <= 131072:
+        order = torch.empty(C * T, device=dev, dtype=torch.int32)
+        n_long = torch.empty(3, device=dev, dtype=torch.int32)  # size classes of the order
+        with torch.cuda.device(dev), B.timed("gs_raster_tile_order", dev):
+            B.check(lib.gs_raster_tile_order(C * T, None, 0, B.ptr(counts), B.ptr(order), B.ptr(n_long), st),
+                    "gs_raster_tile_order")
     n_isects = int(total.item())  # the one host sync of the pipeline (gsplat has the same one)
     isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64)
     flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
     if n_isects == 0:
-        return isect_ids, flatten_ids, offsets
+        return isect_ids, flatten_ids, offsets, None
     pairs = torch.empty(n_isects, device=dev, dtype=torch.int64)
     with torch.cuda.device(dev), B.timed("gs_isect_bin_scatter", dev):
         B.check(lib.gs_isect_bin_scatter(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss), n_slices,
                                          B.ptr(table), B.ptr(offsets), B.ptr(pairs), st), "gs_isect_bin_scatter")
     with torch.cuda.device(dev), B.timed("gs_isect_tile_sort", dev):
-        B.check(lib.gs_isect_tile_sort(C, tile_width, tile_height, B.ptr(offsets), n_isects, B.ptr(pairs),
-                                       B.ptr(isect_ids), B.ptr(flatten_ids), st), "gs_isect_tile_sort")
-    return isect_ids, flatten_ids, offsets
+        B.check(lib.gs_isect_tile_sort(C, tile_width, tile_height, B.ptr(offsets), n_isects, B.ptr(order), B.ptr(n_long),
+                                       B.ptr(pairs), B.ptr(isect_ids), B.ptr(flatten_ids), st), "gs_isect_tile_sort")
+    return isect_ids, flatten_ids, offsets, order
 
 
 def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
@@ -336,8 +345,9 @@ class _RasterizeSplats(torch.autograd.Function):
         C, N = tiles_per_gauss.shape
         TW, TH = math.ceil(width / tile_size), math.ceil(height / tile_size)
         if TW * TH <= int(B.lib().gs_isect_bin_max_tiles()) and os.environ.get("GS_ISECT", "bin") == "bin":
-            isect_ids, flatten_ids, offsets = isect_tiles_binned(splats, tiles_per_gauss, TW, TH)
+            isect_ids, flatten_ids, offsets, order = isect_tiles_binned(splats, tiles_per_gauss, TW, TH)
         else:
+            order = None
             isect_ids, flatten_ids = isect_tiles_from_splats(splats, tiles_per_gauss, TW, TH)
             offsets = isect_offset_encode(isect_ids, C, TW, TH)
         bg = B.f32c(backgrounds) if backgrounds is not None else None
@@ -358,12 +368,15 @@ class _RasterizeSplats(torch.autograd.Function):
                 ctx.v_ready.record(side)
         # longest-first tile schedule: by list length now, by the walked length (written by the forward) for backward
         n_tiles = C * TH * TW
-        order = work = None
+        work = None
+        if n_isects == 0:
+            order = None
         if n_isects > 0 and n_tiles <= 131072:
-            order = torch.empty(n_tiles, device=dev, dtype=torch.int32)
             work = torch.empty(n_tiles, device=dev, dtype=torch.int32) if ctx.needs_input_grad[0] else None
+        if n_isects > 0 and n_tiles <= 131072 and order is None:
+            order = torch.empty(n_tiles, device=dev, dtype=torch.int32)
             with torch.cuda.device(dev), B.timed("gs_raster_tile_order", dev):
-                B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, None, B.ptr(order),
+                B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, None, B.ptr(order), None,
                                                      B.stream_handle(dev)), "gs_raster_tile_order")
         with torch.cuda.device(dev), B.timed("gs_rasterize_fwd", dev):
             B.check(B.lib().gs_rasterize_fwd(C, width, height, tile_size, channels, B.ptr(splats), B.ptr(offsets),
@@ -372,7 +385,7 @@ class _RasterizeSplats(torch.autograd.Function):
                     "gs_rasterize_fwd")
         if work is not None:
             with torch.cuda.device(dev), B.timed("gs_raster_tile_order", dev):
-                B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, B.ptr(work), B.ptr(order),
+                B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, B.ptr(work), B.ptr(order), None,
                                                      B.stream_handle(dev)), "gs_raster_tile_order")
         ctx.tile_order = order if work is not None else None
         ctx.geom = (C, N, width, height, tile_size, channels, int(ed), bool(absgrad))

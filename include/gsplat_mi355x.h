@@ -206,6 +206,8 @@ int gs_isect_bin_scatter(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, c
                          const int32_t* tiles_per_gauss, int32_t n_slices, const uint32_t* table,
                          const int32_t* isect_offsets, uint64_t* pairs, void* stream);
 int gs_isect_tile_sort(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets, int64_t n_isects,
+                       const int32_t* tile_order /* launch order from gs_raster_tile_order, or NULL */,
+                       const int32_t* size_classes /* its size_classes output (device int32[3]), or NULL */,
                        uint64_t* pairs, int64_t* isect_ids /* out [n_isects] */, int32_t* flatten_ids /* out */,
                        void* stream);
 
@@ -243,7 +245,10 @@ int gs_rasterize_bwd(int32_t C, int32_t width, int32_t height, int32_t tile_size
  * `tile_work` when given (written by gs_rasterize_fwd), else by list length from isect_offsets. No reference
  * counterpart: gsplat launches tiles in grid order. */
 int gs_raster_tile_order(int32_t n_tiles, const int32_t* isect_offsets, int64_t n_isects,
-                         const int32_t* tile_work, int32_t* tile_order, void* stream);
+                         const int32_t* tile_work, int32_t* tile_order,
+                         int32_t* size_classes /* out, device int32[3] or NULL: #tiles with cost > 2048, > 1024, > 512;
+                                                  the order is class-major, so these delimit contiguous ranges */,
+                         void* stream);
 
 /* ---- packed mode ------------------------------------------------------------------------------ */
 /* Emits, in ascending (camera, gaussian) order, the rows with radii > 0. cum_excl = exclusive scan of

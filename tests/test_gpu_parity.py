@@ -88,6 +88,85 @@ def test_scan_and_radix_sort(gpu_device):
         assert np.array_equal(k.cpu().numpy(), keys[order]), (n, bits)
 
 
+def _synthetic_records(rng, C, N, TW, TH, hot_tile_rows, depth_levels, dev):
+    """Splat records carrying only what the intersection stage reads: depth [10] and the tile box [13], [14]."""
+    from gsplat import _backend as B
+
+    x0 = rng.integers(0, TW, size=(C, N))
+    y0 = rng.integers(0, TH, size=(C, N))
+    w = rng.integers(1, 4, size=(C, N))
+    h = rng.integers(1, 4, size=(C, N))
+    big = rng.random((C, N)) < 0.01  # a few boxes above the cooperative threshold (> 16 tiles)
+    w = np.where(big, rng.integers(5, max(6, TW), size=(C, N)), w)
+    h = np.where(big, rng.integers(4, max(5, TH), size=(C, N)), h)
+    x1 = np.minimum(x0 + w, TW)
+    y1 = np.minimum(y0 + h, TH)
+    # pile `hot_tile_rows` rows of camera 0 onto tile (1, 1): a segment longer than the LDS classes
+    x0[0, :hot_tile_rows], y0[0, :hot_tile_rows] = 1, 1
+    x1[0, :hot_tile_rows], y1[0, :hot_tile_rows] = 2, 2
+    visible = rng.random((C, N)) < 0.6
+    visible[0, :hot_tile_rows] = True
+    tiles = np.where(visible, (x1 - x0) * (y1 - y0), 0).astype(np.int32)
+    # few distinct depths -> many exact ties, which must come out in ascending flat row id
+    depth = (0.5 + rng.integers(0, depth_levels, size=(C, N)) * 0.37).astype(np.float32)
+    rec = np.zeros((C, N, B.GS_REC), dtype=np.float32)
+    rec[..., 10] = depth
+    rec[..., 13] = (x0 | (y0 << 16)).astype(np.int32).view(np.float32)
+    rec[..., 14] = (x1 | (y1 << 16)).astype(np.int32).view(np.float32)
+    ref_keys, ref_ids = [], []
+    tile_bits = int(math.floor(math.log2(TW * TH))) + 1
+    dbits = depth.view(np.int32).astype(np.int64)
+    for c in range(C):
+        for n in np.nonzero(tiles[c])[0]:
+            ys, xs = np.meshgrid(np.arange(y0[c, n], y1[c, n]), np.arange(x0[c, n], x1[c, n]), indexing="ij")
+            t = (ys * TW + xs).reshape(-1).astype(np.int64)
+            ref_keys.append((np.int64(c) << (32 + tile_bits)) | (t << 32) | dbits[c, n])
+            ref_ids.append(np.full(t.shape, c * N + n, dtype=np.int32))
+    keys = np.concatenate(ref_keys) if ref_keys else np.zeros(0, np.int64)
+    ids = np.concatenate(ref_ids) if ref_ids else np.zeros(0, np.int32)
+    order = np.argsort(keys, kind="stable")  # emission order is ascending flat row id (Appendix A.3)
+    keys, ids = keys[order], ids[order]
+    lin = (keys >> (32 + tile_bits)) * (TW * TH) + ((keys >> 32) & ((1 << tile_bits) - 1))
+    offsets = np.searchsorted(lin, np.arange(C * TW * TH), side="left").astype(np.int32)
+    return (torch.from_numpy(rec).to(dev), torch.from_numpy(tiles).to(dev), keys, ids, offsets.reshape(C, TH, TW))
+
+
+@pytest.mark.parametrize("C,N,TW,TH,hot,levels", [
+    (2, 20_000, 13, 7, 6000, 5),      # global-scratch segment (> 4096), LDS classes, heavy ties
+    (1, 3_000, 5, 4, 1500, 1 << 20),  # mid class (1024 < n <= 4096), nearly no ties
+    (3, 500, 78, 24, 0, 3),           # wide tile grid, short segments, many empty tiles
+    (1, 1, 2, 2, 1, 1),
+])
+def test_binned_isect_matches_stable_sort(gpu_device, C, N, TW, TH, hot, levels):
+    """Both intersection pipelines (binned; emit + full-width radix sort + offset_encode) against numpy's stable sort of
+    the (camera|tile|depth) keys: isect_ids, flatten_ids and isect_offsets bit for bit."""
+    from gsplat.cuda._wrapper import isect_offset_encode, isect_tiles_binned, isect_tiles_from_splats
+
+    rng = np.random.default_rng(C * 1000 + N)
+    rec, tiles, keys, ids, offsets = _synthetic_records(rng, C, N, TW, TH, hot, levels, gpu_device)
+    for _ in range(2):  # the scatter order inside a segment is arbitrary; the result must not be
+        k, f, o, order = isect_tiles_binned(rec, tiles, TW, TH)
+        assert np.array_equal(k.cpu().numpy(), keys)
+        assert np.array_equal(f.cpu().numpy(), ids)
+        assert np.array_equal(o.cpu().numpy(), offsets)
+        if order is not None:
+            assert np.array_equal(np.sort(order.cpu().numpy()), np.arange(C * TW * TH))
+    k2, f2 = isect_tiles_from_splats(rec, tiles, TW, TH)
+    assert np.array_equal(k2.cpu().numpy(), keys)
+    assert np.array_equal(f2.cpu().numpy(), ids)
+    assert np.array_equal(isect_offset_encode(k2, C, TW, TH).cpu().numpy(), offsets)
+
+
+def test_binned_isect_empty(gpu_device):
+    from gsplat import _backend as B
+    from gsplat.cuda._wrapper import isect_tiles_binned
+
+    rec = torch.zeros(2, 100, B.GS_REC, device=gpu_device)
+    tiles = torch.zeros(2, 100, dtype=torch.int32, device=gpu_device)
+    k, f, o, _ = isect_tiles_binned(rec, tiles, 4, 3)
+    assert k.numel() == 0 and f.numel() == 0 and int(o.abs().sum()) == 0 and o.shape == (2, 3, 4)
+
+
 # --------------------------------------------------------------------------------------------- staged pipeline
 def _run_gpu_stages(g, vm, Ks, W, H, dev, mode="antialiased", sh_degree=3, render_mode="RGB+ED",
                     near=0.1, radius_clip=0.0, backgrounds=None):
