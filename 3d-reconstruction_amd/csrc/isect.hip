@@ -43,31 +43,14 @@ __device__ __forceinline__ int64_t block_excl_scan(int64_t v, int64_t& total, in
   return base + incl - v;
 }
 
-// Value source of the scan:  SCAN_PLAIN  v = in[i]
-//                            SCAN_FLAGS  v = (in[i] > 0) in the low 32 bits and in[i] in the high 32 bits, so one
-//                                        pass yields the exclusive scan of the flags AND both totals (count, sum)
-//                            SCAN_GATHER v = in[gather[i]]
-enum { SCAN_PLAIN = 0, SCAN_FLAGS = 1, SCAN_GATHER = 2 };
-
-template <int MODE>
-__device__ __forceinline__ int64_t scan_value(const int32_t* __restrict__ in, const uint32_t* __restrict__ gather,
-                                              int64_t i) {
-  if constexpr (MODE == SCAN_GATHER) return in[gather[i]];
-  const int32_t v = in[i];
-  if constexpr (MODE == SCAN_FLAGS) return v > 0 ? (((int64_t)v << 32) | 1) : 0;
-  return v;
-}
-
-template <int MODE>
-__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const int32_t* __restrict__ in,
-                                                                   const uint32_t* __restrict__ gather, int64_t n,
+__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const int32_t* __restrict__ in, int64_t n,
                                                                    int64_t* __restrict__ block_sums) {
   __shared__ int64_t sh[4];
   const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
   int64_t s = 0;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; ++i)
-    if (base + i < n) s += scan_value<MODE>(in, gather, base + i);
+    if (base + i < n) s += in[base + i];
   int64_t total;
   block_excl_scan(s, total, sh);
   if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
@@ -89,57 +72,41 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(int64_t* 
   if (threadIdx.x == 0) *total_out = carry;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(const int32_t* __restrict__ in,
-                                                                  const uint32_t* __restrict__ gather, int64_t n,
+__global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(const int32_t* __restrict__ in, int64_t n,
                                                                   const int64_t* __restrict__ block_sums,
                                                                   int32_t* __restrict__ out) {
   __shared__ int64_t sh[4];
   const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-  int64_t v[SCAN_ITEMS];
+  int32_t v[SCAN_ITEMS];
   int64_t s = 0;
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; ++i) {
-    v[i] = (base + i < n) ? scan_value<MODE>(in, gather, base + i) : 0;
+    v[i] = (base + i < n) ? in[base + i] : 0;
     s += v[i];
   }
   int64_t total;
   int64_t ex = block_excl_scan(s, total, sh) + block_sums[blockIdx.x];
 #pragma unroll
   for (int i = 0; i < SCAN_ITEMS; ++i) {
-    if (base + i < n) out[base + i] = (int32_t)(uint32_t)ex;  // SCAN_FLAGS: low word = flag prefix
+    if (base + i < n) out[base + i] = (int32_t)ex;
     ex += v[i];
   }
-}
-
-// splits the packed SCAN_FLAGS total into totals[0] = count, totals[1] = sum
-__global__ void scan_split_total_kernel(const int64_t* __restrict__ packed, int64_t* __restrict__ totals) {
-  const int64_t t = *packed;
-  totals[0] = t & 0xffffffffll;
-  totals[1] = t >> 32;
 }
 
 // ------------------------------------------------------------------------------------------ emit
 // One lane per (camera, Gaussian).  Gaussians covering > 16 tiles are emitted cooperatively by the
 // whole wave (contiguous 512-B key stores); small ones by their own lane.
-//
-// ORDERED = false: slot s IS the flat row idx = c*N + n, cum_excl is indexed by idx (A.3 emission order).
-// ORDERED = true : slot s walks `order` (the visible rows sorted by (camera, depth)), cum_excl is indexed by s.
-//                  Emitting in depth order lets the following stable sort look at the (camera|tile) bits only.
-template <bool ORDERED>
 __global__ __launch_bounds__(256) void isect_emit_kernel(int32_t N, int64_t n_slots, int32_t tile_w, int32_t tile_n_bits,
                                                          const float* __restrict__ splats,
                                                          const int32_t* __restrict__ tiles_per_gauss,
-                                                         const uint32_t* __restrict__ order,
                                                          const int32_t* __restrict__ cum_excl,
                                                          int64_t* __restrict__ isect_ids,
                                                          int32_t* __restrict__ flatten_ids) {
   const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int64_t idx = slot;
+  const int64_t idx = slot;  // flat row id c*N + n (A.3 emission order)
   int cnt = 0, x0 = 0, y0 = 0, wdt = 1;
   int64_t base = 0, key_hi = 0;
   if (slot < n_slots) {
-    if constexpr (ORDERED) idx = order[slot];
     cnt = tiles_per_gauss[idx];
     if (cnt > 0) {
       const float4 r2 = reinterpret_cast<const float4*>(splats + idx * REC)[2];
@@ -201,23 +168,6 @@ __global__ __launch_bounds__(256) void offset_encode_kernel(int64_t n_isects, co
   }
 }
 
-// ------------------------------------------------------------------------------------------ depth pre-sort
-// Compacts the rows that touch at least one tile into (key = camera << 32 | depth bits, order = flat row id),
-// ascending row id.  Depths are > 0 here (near-plane cull), so the IEEE bit pattern orders like the value.
-__global__ __launch_bounds__(256) void depth_keys_kernel(int32_t N, int64_t total,
-                                                         const int32_t* __restrict__ tiles_per_gauss,
-                                                         const int32_t* __restrict__ cum_vis,
-                                                         const float* __restrict__ splats,
-                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ order) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  if (tiles_per_gauss[idx] <= 0) return;
-  const int64_t o = cum_vis[idx];
-  const uint32_t dbits = (uint32_t)__float_as_int(splats[idx * REC + 10]);
-  keys[o] = ((uint64_t)(idx / N) << 32) | dbits;
-  order[o] = (uint32_t)idx;
-}
-
 // ------------------------------------------------------------------------------------------ packed mode
 __global__ __launch_bounds__(256) void mark_visible_kernel(int64_t n, const int32_t* __restrict__ radii,
                                                            int32_t* __restrict__ visible) {
@@ -262,19 +212,6 @@ extern "C" int64_t gs_exclusive_scan_workspace_bytes(int64_t n) {
   return (gs::ceil_div(n, gs::SCAN_TILE) + 1) * (int64_t)sizeof(int64_t);
 }
 
-template <int MODE>
-static int scan_launch(const int32_t* in, const uint32_t* gather, int32_t* out, int64_t n, int64_t* total,
-                       void* workspace, int64_t workspace_bytes, hipStream_t s) {
-  if (workspace_bytes < gs_exclusive_scan_workspace_bytes(n)) return GS_ERR_WORKSPACE;
-  const int64_t nb = gs::ceil_div(n, gs::SCAN_TILE);
-  int64_t* sums = (int64_t*)workspace;
-  hipLaunchKernelGGL((gs::scan_reduce_kernel<MODE>), dim3((unsigned)nb), dim3(gs::SCAN_THREADS), 0, s, in, gather, n, sums);
-  hipLaunchKernelGGL(gs::scan_block_sums_kernel, dim3(1), dim3(gs::SCAN_THREADS), 0, s, sums, nb, total);
-  hipLaunchKernelGGL((gs::scan_final_kernel<MODE>), dim3((unsigned)nb), dim3(gs::SCAN_THREADS), 0, s, in, gather, n, sums, out);
-  GS_CHECK_LAUNCH();
-  return GS_OK;
-}
-
 extern "C" int gs_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int64_t* total, void* workspace,
                                      int64_t workspace_bytes, void* stream) {
   if (n < 0 || !total) return GS_ERR_INVALID_ARG;
@@ -284,51 +221,14 @@ extern "C" int gs_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n,
     return GS_OK;
   }
   if (!in || !out || !workspace) return GS_ERR_INVALID_ARG;
-  return scan_launch<gs::SCAN_PLAIN>(in, nullptr, out, n, total, workspace, workspace_bytes, s);
-}
-
-extern "C" int gs_isect_count_visible(const int32_t* tiles_per_gauss, int64_t n, int32_t* cum_vis, int64_t* totals,
-                                      void* workspace, int64_t workspace_bytes, void* stream) {
-  if (n < 0 || !totals) return GS_ERR_INVALID_ARG;
-  if (n >= ((int64_t)1 << 31)) return GS_ERR_UNSUPPORTED;
-  hipStream_t s = (hipStream_t)stream;
-  if (n == 0) {
-    GS_HIP(hipMemsetAsync(totals, 0, 2 * sizeof(int64_t), s));
-    return GS_OK;
-  }
-  if (!tiles_per_gauss || !cum_vis || !workspace) return GS_ERR_INVALID_ARG;
-  // the packed (sum << 32 | count) total lands in totals[1] first, then is split in place
-  int st = scan_launch<gs::SCAN_FLAGS>(tiles_per_gauss, nullptr, cum_vis, n, totals + 1, workspace, workspace_bytes, s);
-  if (st != GS_OK) return st;
-  hipLaunchKernelGGL(gs::scan_split_total_kernel, dim3(1), dim3(1), 0, s, totals + 1, totals);
+  if (workspace_bytes < gs_exclusive_scan_workspace_bytes(n)) return GS_ERR_WORKSPACE;
+  const int64_t nb = gs::ceil_div(n, gs::SCAN_TILE);
+  int64_t* sums = (int64_t*)workspace;
+  hipLaunchKernelGGL(gs::scan_reduce_kernel, dim3((unsigned)nb), dim3(gs::SCAN_THREADS), 0, s, in, n, sums);
+  hipLaunchKernelGGL(gs::scan_block_sums_kernel, dim3(1), dim3(gs::SCAN_THREADS), 0, s, sums, nb, total);
+  hipLaunchKernelGGL(gs::scan_final_kernel, dim3((unsigned)nb), dim3(gs::SCAN_THREADS), 0, s, in, n, sums, out);
   GS_CHECK_LAUNCH();
   return GS_OK;
-}
-
-extern "C" int gs_isect_depth_keys(int32_t C, int32_t N, const int32_t* tiles_per_gauss, const int32_t* cum_vis,
-                                   const float* splats, uint64_t* keys, uint32_t* order, void* stream) {
-  if (C < 1 || N < 0) return GS_ERR_INVALID_ARG;
-  if (N == 0) return GS_OK;
-  if (!tiles_per_gauss || !cum_vis || !splats || !keys || !order) return GS_ERR_INVALID_ARG;
-  const int64_t total = (int64_t)C * N;
-  if (total >= ((int64_t)1 << 31)) return GS_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(gs::depth_keys_kernel, dim3((unsigned)gs::ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                     N, total, tiles_per_gauss, cum_vis, splats, keys, order);
-  GS_CHECK_LAUNCH();
-  return GS_OK;
-}
-
-extern "C" int gs_isect_scan_ordered(const int32_t* tiles_per_gauss, const uint32_t* order, int64_t n_visible,
-                                     int32_t* cum_ordered, int64_t* total, void* workspace, int64_t workspace_bytes,
-                                     void* stream) {
-  if (n_visible < 0 || !total) return GS_ERR_INVALID_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  if (n_visible == 0) {
-    GS_HIP(hipMemsetAsync(total, 0, sizeof(int64_t), s));
-    return GS_OK;
-  }
-  if (!tiles_per_gauss || !order || !cum_ordered || !workspace) return GS_ERR_INVALID_ARG;
-  return scan_launch<gs::SCAN_GATHER>(tiles_per_gauss, order, cum_ordered, n_visible, total, workspace, workspace_bytes, s);
 }
 
 static int emit_check(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, int* tile_n_bits) {
@@ -349,26 +249,9 @@ extern "C" int gs_isect_emit(int32_t C, int32_t N, int32_t tile_w, int32_t tile_
   if (N == 0) return GS_OK;
   if (!splats || !tiles_per_gauss || !cum_excl || !isect_ids || !flatten_ids) return GS_ERR_INVALID_ARG;
   const int64_t total = (int64_t)C * N;
-  hipLaunchKernelGGL((gs::isect_emit_kernel<false>), dim3((unsigned)gs::ceil_div(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, N, total, tile_w, tile_n_bits, splats, tiles_per_gauss,
-                     (const uint32_t*)nullptr, cum_excl, isect_ids, flatten_ids);
-  GS_CHECK_LAUNCH();
-  return GS_OK;
-}
-
-extern "C" int gs_isect_emit_ordered(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, const float* splats,
-                                     const int32_t* tiles_per_gauss, const uint32_t* order, int64_t n_visible,
-                                     const int32_t* cum_ordered, int64_t* isect_ids, int32_t* flatten_ids,
-                                     void* stream) {
-  int tile_n_bits;
-  int st = emit_check(C, N, tile_w, tile_h, &tile_n_bits);
-  if (st != GS_OK) return st;
-  if (n_visible < 0 || n_visible > (int64_t)C * N) return GS_ERR_INVALID_ARG;
-  if (n_visible == 0) return GS_OK;
-  if (!splats || !tiles_per_gauss || !order || !cum_ordered || !isect_ids || !flatten_ids) return GS_ERR_INVALID_ARG;
-  hipLaunchKernelGGL((gs::isect_emit_kernel<true>), dim3((unsigned)gs::ceil_div(n_visible, 256)), dim3(256), 0,
-                     (hipStream_t)stream, N, n_visible, tile_w, tile_n_bits, splats, tiles_per_gauss, order,
-                     cum_ordered, isect_ids, flatten_ids);
+  hipLaunchKernelGGL(gs::isect_emit_kernel, dim3((unsigned)gs::ceil_div(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, N, total, tile_w, tile_n_bits, splats, tiles_per_gauss, cum_excl, isect_ids,
+                     flatten_ids);
   GS_CHECK_LAUNCH();
   return GS_OK;
 }

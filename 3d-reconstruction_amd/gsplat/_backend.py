@@ -46,10 +46,6 @@ _SIGNATURES = {
     "gs_exclusive_scan_workspace_bytes": (c_int64, [c_int64]),
     "gs_exclusive_scan_i32": (ctypes.c_int, [_P, _P, c_int64, _P, _P, c_int64, _P]),
     "gs_isect_emit": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
-    "gs_isect_count_visible": (ctypes.c_int, [_P, c_int64, _P, _P, _P, c_int64, _P]),
-    "gs_isect_depth_keys": (ctypes.c_int, [c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
-    "gs_isect_scan_ordered": (ctypes.c_int, [_P, _P, c_int64, _P, _P, _P, c_int64, _P]),
-    "gs_isect_emit_ordered": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "gs_isect_bin_max_tiles": (c_int32, []),
     "gs_isect_bin_count": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, c_int32, _P, _P]),
     "gs_isect_bin_offsets": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P]),

@@ -12,7 +12,6 @@ from __future__ import annotations
 
 import ctypes
 import math
-import os
 from typing import Optional, Tuple
 
 import torch
@@ -220,63 +219,26 @@ def _key_bits(n_cameras: int, tile_width: int, tile_height: int) -> Tuple[int, i
 
 def isect_tiles_from_splats(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int, tile_height: int,
                             sort: bool = True) -> Tuple[Tensor, Tensor]:
-    """isect_tiles pass 2 (+ sort) from splat records (tile boxes were computed by the projection kernel).
-    Returns (isect_ids int64 [I], flatten_ids int32 [I]).
-
-    sort=False: A.3's emission order (ascending flat row id c*N+n), unsorted.
-    sort=True : the result of A.3's stable sort on the (camera|tile|depth) key, produced as
-                depth pre-sort of the V visible rows -> emission in that order -> stable sort on the (camera|tile)
-                bits only; identical output, but the I-sized array is swept 2x instead of 6x."""
+    """gsplat's own isect_tiles decomposition from splat records (tile boxes were computed by the projection kernel):
+    cumsum -> emission in ascending flat row id -> stable radix sort on the (camera|tile|depth) key (Appendix A.3).
+    Returns (isect_ids int64 [I], flatten_ids int32 [I]).  The rasterization path uses `isect_tiles_binned`, which
+    produces the same arrays; this one is the generic route (any tile count) and its cross-check."""
     dev = B.require_gpu(splats, tiles_per_gauss)
     C, N = tiles_per_gauss.shape
-    tile_n_bits, cam_n_bits = _key_bits(C, tile_width, tile_height)
-    if not sort:
-        cum, total = exclusive_scan_i32(tiles_per_gauss)
-        n_isects = int(total.item())
-        isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64)
-        flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
-        if n_isects:
-            with torch.cuda.device(dev), B.timed("gs_isect_emit", dev):
-                B.check(B.lib().gs_isect_emit(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
-                                              B.ptr(cum), B.ptr(isect_ids), B.ptr(flatten_ids), B.stream_handle(dev)),
-                        "gs_isect_emit")
-        return isect_ids, flatten_ids
-
-    lib, st = B.lib(), B.stream_handle(dev)
-    n = C * N
-    cum_vis = torch.empty(n, device=dev, dtype=torch.int32)
-    totals = torch.empty(2, device=dev, dtype=torch.int64)
-    wsb = int(lib.gs_exclusive_scan_workspace_bytes(n))
-    ws = torch.empty(max(wsb, 8), device=dev, dtype=torch.uint8)
-    with torch.cuda.device(dev), B.timed("gs_isect_count_visible", dev):
-        B.check(lib.gs_isect_count_visible(B.ptr(tiles_per_gauss), n, B.ptr(cum_vis), B.ptr(totals), B.ptr(ws), wsb, st),
-                "gs_isect_count_visible")
-    # everything up to the depth pre-sort is enqueued with the visible count still on the device (buffers sized for the
-    # worst case C*N), so the one host sync of the pipeline (gsplat has the same one) overlaps with that work
-    dkeys = torch.empty(n, device=dev, dtype=torch.int64)
-    order = torch.empty(n, device=dev, dtype=torch.int32)
-    with torch.cuda.device(dev), B.timed("gs_isect_depth_keys", dev):
-        B.check(lib.gs_isect_depth_keys(C, N, B.ptr(tiles_per_gauss), B.ptr(cum_vis), B.ptr(splats), B.ptr(dkeys),
-                                        B.ptr(order), st), "gs_isect_depth_keys")
-    # positive floats: bit 31 is 0, so a single camera needs 31 bits only
-    _, order = radix_sort_pairs(dkeys, order, 31 if C == 1 else 32 + cam_n_bits,
-                                label="gs_radix_sort_pairs_u64_u32[depth]", n_dev=totals[0:1])
-    n_vis, n_isects = (int(v) for v in totals.tolist())
+    cum, total = exclusive_scan_i32(tiles_per_gauss)
+    n_isects = int(total.item())  # host sync (gsplat has the same one)
     isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64)
     flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
     if n_isects == 0:
         return isect_ids, flatten_ids
-    cum_ord = torch.empty(n_vis, device=dev, dtype=torch.int32)
-    total_ord = torch.empty(1, device=dev, dtype=torch.int64)  # == n_isects again
-    with torch.cuda.device(dev), B.timed("gs_isect_scan_ordered", dev):
-        B.check(lib.gs_isect_scan_ordered(B.ptr(tiles_per_gauss), B.ptr(order), n_vis, B.ptr(cum_ord), B.ptr(total_ord),
-                                          B.ptr(ws), wsb, st), "gs_isect_scan_ordered")
-    with torch.cuda.device(dev), B.timed("gs_isect_emit_ordered", dev):
-        B.check(lib.gs_isect_emit_ordered(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
-                                          B.ptr(order), n_vis, B.ptr(cum_ord), B.ptr(isect_ids), B.ptr(flatten_ids), st),
-                "gs_isect_emit_ordered")
-    return radix_sort_pairs(isect_ids, flatten_ids, 32 + tile_n_bits + cam_n_bits, begin_bit=32,
-                            label="gs_radix_sort_pairs_u64_u32[tile]")
+    with torch.cuda.device(dev), B.timed("gs_isect_emit", dev):
+        B.check(B.lib().gs_isect_emit(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
+                                      B.ptr(cum), B.ptr(isect_ids), B.ptr(flatten_ids), B.stream_handle(dev)),
+                "gs_isect_emit")
+    if sort:
+        tile_n_bits, cam_n_bits = _key_bits(C, tile_width, tile_height)
+        isect_ids, flatten_ids = radix_sort_pairs(isect_ids, flatten_ids, 32 + tile_n_bits + cam_n_bits)
+    return isect_ids, flatten_ids
 
 
 def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
@@ -290,7 +252,6 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
     T = tile_width * tile_height
     lib, st = B.lib(), B.stream_handle(dev)
     n_slices = max(1, min(512, max(1024 // C, 1), -(-max(N, 1) // 2048)))
-    n_slices = int(os.environ.get('GS_SLICES', n_slices))
     table = torch.empty(C * n_slices * T, device=dev, dtype=torch.int32)
     counts = torch.empty(C * T, device=dev, dtype=torch.int32)
     offsets = torch.empty(C, tile_height, tile_width, device=dev, dtype=torch.int32)
@@ -344,7 +305,7 @@ class _RasterizeSplats(torch.autograd.Function):
         dev = B.require_gpu(splats)
         C, N = tiles_per_gauss.shape
         TW, TH = math.ceil(width / tile_size), math.ceil(height / tile_size)
-        if TW * TH <= int(B.lib().gs_isect_bin_max_tiles()) and os.environ.get("GS_ISECT", "bin") == "bin":
+        if TW * TH <= int(B.lib().gs_isect_bin_max_tiles()):
             isect_ids, flatten_ids, offsets, order = isect_tiles_binned(splats, tiles_per_gauss, TW, TH)
         else:
             order = None

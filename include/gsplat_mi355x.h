@@ -135,29 +135,6 @@ int gs_isect_emit(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h,
                   int32_t* flatten_ids,            /* out [n_isects] */
                   void* stream);
 
-/* Depth-pre-sorted emission (same sorted result as gs_isect_emit + a full-width sort, 4 fewer big passes):
- *   gs_isect_count_visible : cum_vis = exclusive scan of (tiles_per_gauss > 0); totals[0] = #visible rows V,
- *                            totals[1] = sum(tiles_per_gauss) = n_isects (device int64[2])
- *   gs_isect_depth_keys    : keys[V] = camera << 32 | depth bits, order[V] = flat row id (ascending)
- *   -> gs_radix_sort_pairs_u64_u32 on bits [0, 32 + cam_n_bits) sorts `order` by (camera, depth), stable
- *   gs_isect_scan_ordered  : cum_ordered[s] = exclusive scan of tiles_per_gauss[order[s]]
- *   gs_isect_emit_ordered  : as gs_isect_emit, walking `order`; afterwards a STABLE sort on key bits
- *                            [32, 32 + tile_n_bits + cam_n_bits) (gs_radix_sort_pairs_u64_u32_bits) yields exactly the
- *                            order of A.3's sort on bits [0, 32 + tile_n_bits + cam_n_bits): (camera, tile, depth), ties
- *                            by ascending flat row id. Same reference stage as gs_isect_emit (8a rows 5, 6). */
-int gs_isect_count_visible(const int32_t* tiles_per_gauss, int64_t n, int32_t* cum_vis,
-                           int64_t* totals, /* out, device, 2 elements */
-                           void* workspace, int64_t workspace_bytes /* gs_exclusive_scan_workspace_bytes(n) */,
-                           void* stream);
-int gs_isect_depth_keys(int32_t C, int32_t N, const int32_t* tiles_per_gauss, const int32_t* cum_vis,
-                        const float* splats, uint64_t* keys, uint32_t* order, void* stream);
-int gs_isect_scan_ordered(const int32_t* tiles_per_gauss, const uint32_t* order, int64_t n_visible,
-                          int32_t* cum_ordered, int64_t* total, void* workspace, int64_t workspace_bytes,
-                          void* stream);
-int gs_isect_emit_ordered(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, const float* splats,
-                          const int32_t* tiles_per_gauss, const uint32_t* order, int64_t n_visible,
-                          const int32_t* cum_ordered, int64_t* isect_ids, int32_t* flatten_ids, void* stream);
-
 int64_t gs_radix_sort_workspace_bytes(int64_t n);
 /* Stable LSD radix sort of (key,value) pairs on key bits [0,end_bit).  Ping-pongs between the a and b
  * buffers; *result_in_b_host (HOST int) says which pair holds the sorted output. */

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
 
     lib = ctypes.CDLL(B.lib_path())
     declared = _declared_symbols()
-    assert len(declared) == 16, declared
+    assert len(declared) == 24, declared
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/gsplat_mi355x.h but not exported"
     assert set(declared) == set(B.EXPORTED_SYMBOLS), set(declared) ^ set(B.EXPORTED_SYMBOLS)
@@ -30,7 +30,8 @@ def test_library_exports_every_declared_symbol():
     assert B.lib().gs_error_string(-2).decode().startswith("gsplat_mi355x")
     # pure host-side entry points (no GPU needed)
     assert B.lib().gs_exclusive_scan_workspace_bytes(5_000_000) >= 8 * (5_000_000 // 2048)
-    assert B.lib().gs_radix_sort_workspace_bytes(10_000_000) > 2 * 256 * 4 * (10_000_000 // 4096)
+    assert B.lib().gs_radix_sort_workspace_bytes(10_000_000) >= 512 * 4 * (10_000_000 // 4096)
+    assert B.lib().gs_isect_bin_max_tiles() >= 9600  # 1920x1280 / 16^2 per camera
 
 
 def test_proj_params_struct_matches_header():
