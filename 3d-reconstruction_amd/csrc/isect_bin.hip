@@ -214,11 +214,13 @@ struct TsShared {
   uint32_t wave_cnt[WAVES][TS_MAX_RADIX];
   uint32_t wsum[4];
   uint32_t red_min[WAVES], red_max[WAVES];
+  uint32_t bstart[TS_MAX_RADIX + 1];
 };
 
 // One stable counting pass on digit (key >> shift) & mask from `in` to `out` (n entries, whole workgroup of WAVES
 // waves; every wave ranks a contiguous chunk, so wave order = input order).
-template <int WAVES, typename RankT>
+// ON_ID selects the sorted field: the depth bits (.x) or the row id (.y).
+template <int WAVES, typename RankT, bool ON_ID>
 __device__ __forceinline__ void ts_pass(const uint2* in, uint2* out, RankT* ranks, int n, int shift, uint32_t mask,
                                         TsShared<WAVES>& sh) {
   constexpr int THREADS = WAVES * 64;
@@ -238,7 +240,7 @@ __device__ __forceinline__ void ts_pass(const uint2* in, uint2* out, RankT* rank
     for (int u = 0; u < U; ++u) {
       const int i = b + u * 64 + lane;
       valid[u] = i < ce;
-      d[u] = valid[u] ? ((in[i].x >> shift) & mask) : 0u;
+      d[u] = valid[u] ? (((ON_ID ? in[i].y : in[i].x) >> shift) & mask) : 0u;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -302,7 +304,7 @@ __device__ __forceinline__ void ts_pass(const uint2* in, uint2* out, RankT* rank
       const int i = b + u * 64 + lane;
       if (i < ce) {
         e[u] = in[i];
-        dst[u] = sh.wave_cnt[wave][(e[u].x >> shift) & mask] + (uint32_t)ranks[i];
+        dst[u] = sh.wave_cnt[wave][((ON_ID ? e[u].y : e[u].x) >> shift) & mask] + (uint32_t)ranks[i];
       }
     }
 #pragma unroll
@@ -312,10 +314,30 @@ __device__ __forceinline__ void ts_pass(const uint2* in, uint2* out, RankT* rank
   __syncthreads();
 }
 
-// Sorts n (depth bits, row id) pairs held in `a` (scratch `b`); returns the buffer that holds the result.
-// Only the key bits that differ inside the segment are sorted (a tile's depths share their high bits), in the
-// fewest passes of at most 9 bits.
-template <int WAVES, typename RankT>
+__device__ __forceinline__ unsigned long long ts_key64(const uint2 e) { return ((unsigned long long)e.x << 32) | e.y; }
+
+template <int WAVES, typename RankT, bool ON_ID>
+__device__ __forceinline__ void ts_lsd(uint2*& cur, uint2*& oth, RankT* ranks, int n, int nbits, TsShared<WAVES>& sh) {
+  const int npass = (nbits + TS_MAX_BITS - 1) / TS_MAX_BITS;
+  const int bpp = npass ? (nbits + npass - 1) / npass : 0;
+#pragma unroll 1
+  for (int shift = 0; shift < nbits; shift += bpp) {
+    const int nb = min(bpp, nbits - shift);
+    ts_pass<WAVES, RankT, ON_ID>(cur, oth, ranks, n, shift, (1u << nb) - 1u, sh);
+    uint2* t = cur; cur = oth; oth = t;
+  }
+}
+
+// Sorts n (depth bits, row id) pairs held in `a` (scratch `b`) ascending by (depth bits, row id) -- A.3's order: the
+// stable sort of an id-ordered emission.  Returns the buffer that holds the result.  Only the bits that differ
+// inside the segment matter (a tile's depths share their high bits).
+//   BUCKETS path (LDS only): one unstable counting pass on the top 9 differing depth bits (LDS atomics), then every
+//     bucket -- a couple of entries when depths spread -- is insertion-sorted on the full 64-bit (depth, id) key by one
+//     lane.  Taken when no bucket exceeds TS_BUCKET_MAX.
+//   LSD path: stable 9-bit counting passes over the differing id bits, then over the differing depth bits.
+constexpr int TS_BUCKET_MAX = 64;
+
+template <int WAVES, typename RankT, bool BUCKETS>
 __device__ __forceinline__ uint2* ts_sort(uint2* a, uint2* b, RankT* ranks, int n, TsShared<WAVES>& sh) {
   constexpr int THREADS = WAVES * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -333,37 +355,116 @@ __device__ __forceinline__ uint2* ts_sort(uint2* a, uint2* b, RankT* ranks, int 
   if (lane == 0) { sh.red_min[wave] = kmin; sh.red_max[wave] = kmax; }
   __syncthreads();
 #pragma unroll
-  for (int w = 0; w < WAVES; ++w) { kmin = min(kmin, sh.red_min[w]); kmax = max(kmax, sh.red_max[w]); }
-  const uint32_t diff = kmin ^ kmax;
-  const int nbits = diff ? 32 - __clz((int)diff) : 0;
-  const int npass = (nbits + TS_MAX_BITS - 1) / TS_MAX_BITS;
-  const int bpp = npass ? (nbits + npass - 1) / npass : 0;
-  uint2* cur = a;
-  uint2* oth = b;
-#pragma unroll 1
-  for (int shift = 0; shift < nbits; shift += bpp) {
-    const int nb = min(bpp, nbits - shift);
-    ts_pass<WAVES, RankT>(cur, oth, ranks, n, shift, (1u << nb) - 1u, sh);
-    uint2* t = cur; cur = oth; oth = t;
+  for (int w = 0; w < WAVES; ++w) {
+    kmin = min(kmin, sh.red_min[w]);
+    kmax = max(kmax, sh.red_max[w]);
   }
-  // equal depths must come out in ascending row id (A.3: stable sort of an id-ordered emission): odd-even
-  // transposition restricted to equal keys, until a full round moves nothing (one round when there are no ties)
-  for (;;) {
-    int moved = 0;
-#pragma unroll 1
-    for (int phase = 0; phase < 2; ++phase) {
-      for (int i = 2 * tid + phase; i + 1 < n; i += 2 * THREADS) {
-        const uint2 lo = cur[i], hi = cur[i + 1];
-        if (lo.x == hi.x && lo.y > hi.y) {
-          cur[i] = hi;
-          cur[i + 1] = lo;
-          moved = 1;
+  const uint32_t kdiff = kmin ^ kmax;
+  const int nbits = kdiff ? 32 - __clz((int)kdiff) : 0;
+  __syncthreads();
+
+  if (BUCKETS) {
+    uint32_t* cnt = &sh.wave_cnt[0][0];
+    for (int i = tid; i < TS_MAX_RADIX; i += THREADS) cnt[i] = 0;
+    __syncthreads();
+    // bucket = position of the depth inside the segment's [min, max] on a LINEAR scale (float bit patterns would put
+    // half of a frustum's depths into a few exponent buckets); any monotone map of the key keeps the partition valid
+    const float dmin = __uint_as_float(kmin);
+    const float bscale = (kmax > kmin) ? (float)(TS_MAX_RADIX - 1) / (__uint_as_float(kmax) - dmin) : 0.f;
+    auto bucket = [&](uint32_t k) -> uint32_t {
+      return (uint32_t)min(TS_MAX_RADIX - 1, (int)((__uint_as_float(k) - dmin) * bscale));
+    };
+    for (int i = tid; i < n; i += THREADS) atomicAdd(&cnt[bucket(a[i].x)], 1u);
+    __syncthreads();
+    constexpr int SCAN_T = THREADS < 256 ? THREADS : 256;
+    constexpr int DPT = TS_MAX_RADIX / SCAN_T;
+    uint32_t tot[DPT], sum = 0, incl = 0, bmax = 0;
+    if (tid < SCAN_T) {
+#pragma unroll
+      for (int j = 0; j < DPT; ++j) {
+        tot[j] = cnt[DPT * tid + j];
+        sum += tot[j];
+        bmax = max(bmax, tot[j]);
+      }
+      incl = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) bmax = max(bmax, (uint32_t)__shfl_xor((int)bmax, o));
+      if (lane == 63) sh.wsum[wave] = incl;
+      if (lane == 0) sh.red_max[wave] = bmax;
+    }
+    __syncthreads();
+    bmax = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_T / 64; ++w) bmax = max(bmax, sh.red_max[w]);
+    if (bmax <= (uint32_t)TS_BUCKET_MAX) {
+      if (tid < SCAN_T) {
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int w = 0; w < SCAN_T / 64; ++w)
+          if (w < wave) run += sh.wsum[w];
+#pragma unroll
+        for (int j = 0; j < DPT; ++j) {
+          sh.bstart[DPT * tid + j] = run;
+          cnt[DPT * tid + j] = run;
+          run += tot[j];
+        }
+        if (tid == SCAN_T - 1) sh.bstart[TS_MAX_RADIX] = (uint32_t)n;
+      }
+      __syncthreads();
+      for (int i = tid; i < n; i += THREADS) {
+        const uint2 e = a[i];
+        b[atomicAdd(&cnt[bucket(e.x)], 1u)] = e;
+      }
+      __syncthreads();
+      for (int d = tid; d < TS_MAX_RADIX; d += THREADS) {
+        const int s0 = (int)sh.bstart[d], s1 = (int)sh.bstart[d + 1];
+        for (int j = s0 + 1; j < s1; ++j) {
+          const uint2 v = b[j];
+          const unsigned long long kv = ts_key64(v);
+          int k = j - 1;
+          while (k >= s0) {
+            const uint2 p = b[k];
+            if (ts_key64(p) <= kv) break;
+            b[k + 1] = p;
+            --k;
+          }
+          b[k + 1] = v;
         }
       }
       __syncthreads();
+      return b;
     }
-    if (!__syncthreads_or(moved)) break;
+    __syncthreads();
   }
+
+  // LSD: the differing id bits first, then the differing depth bits (every pass stable)
+  uint32_t id_or = 0;
+  {
+    // exact differing-bit mask of the ids across the whole segment
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    for (int i = tid; i < n; i += THREADS) { const uint32_t y = a[i].y; lo = min(lo, y); hi = max(hi, y); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lo = min(lo, (uint32_t)__shfl_xor((int)lo, o));
+      hi = max(hi, (uint32_t)__shfl_xor((int)hi, o));
+    }
+    if (lane == 0) { sh.red_min[wave] = lo; sh.red_max[wave] = hi; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) { lo = min(lo, sh.red_min[w]); hi = max(hi, sh.red_max[w]); }
+    id_or = lo ^ hi;
+    __syncthreads();
+  }
+  const int ibits = id_or ? 32 - __clz((int)id_or) : 0;
+  uint2* cur = a;
+  uint2* oth = b;
+  ts_lsd<WAVES, RankT, true>(cur, oth, ranks, n, ibits, sh);
+  ts_lsd<WAVES, RankT, false>(cur, oth, ranks, n, nbits, sh);
   return cur;
 }
 
@@ -399,7 +500,7 @@ __global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(int32_t T, int32_
     if (n <= CAP) {
       for (int i = threadIdx.x; i < n; i += THREADS) buf_a[i] = pairs[start + i];
       __syncthreads();
-      const uint2* cur = ts_sort<WAVES, uint16_t>(buf_a, buf_b, rank_s, n, sh);
+      const uint2* cur = ts_sort<WAVES, uint16_t, true>(buf_a, buf_b, rank_s, n, sh);
       for (int i = threadIdx.x; i < n; i += THREADS) {
         const uint2 e = cur[i];
         isect_ids[start + i] = key_hi | (int64_t)e.x;
@@ -411,7 +512,7 @@ __global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(int32_t T, int32_
       uint2* ga = pairs + start;
       uint2* gb = reinterpret_cast<uint2*>(isect_ids + start);
       uint32_t* gr = reinterpret_cast<uint32_t*>(flatten_ids + start);
-      const uint2* cur = ts_sort<WAVES, uint32_t>(ga, gb, gr, n, sh);
+      const uint2* cur = ts_sort<WAVES, uint32_t, false>(ga, gb, gr, n, sh);
       // every thread converts its own entries; entry i of either buffer maps onto output slot i
       for (int i = threadIdx.x; i < n; i += THREADS) {
         const uint2 e = cur[i];

@@ -115,6 +115,7 @@ def main():
     gen = torch.Generator().manual_seed(1 + rank)
     wc = torch.randn(C, H, W, D, generator=gen).to(dev)
     wa = torch.randn(C, H, W, 1, generator=gen).to(dev)
+    wc_flat, wa_flat = wc.reshape(-1), wa.reshape(-1)
     plist = list(params.values())
 
     def step():
@@ -124,7 +125,8 @@ def main():
             params["means"], params["quats"], params["scales"], params["opacities"], params["colors"], vm, Ks, W, H,
             near_plane=0.1, far_plane=1e10, sh_degree=3, packed=False, render_mode="RGB+ED", absgrad=True,
             rasterize_mode="antialiased")
-        loss = (rc * wc).sum() + (ra * wa).sum()
+        # fixed random linear functional of colours and alphas, as two dot products
+        loss = torch.dot(rc.reshape(-1), wc_flat) + torch.dot(ra.reshape(-1), wa_flat)
         loss.backward()
         if world > 1:
             all_reduce_gradients(plist)
