@@ -489,17 +489,42 @@ __global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(int32_t T, int32_
     k += (CLS > 0) ? size_classes[CLS - 1] : 0;
     k_end = (CLS < 3) ? size_classes[CLS] : n_tiles;
   }
+  // software pipeline over the workgroup's tiles: the next segment's pairs are loaded into registers while the
+  // current one is being sorted in LDS
+  constexpr int ITEMS = CAP / THREADS;
+  uint2 pre[ITEMS];
+  int64_t nx_tile = 0;
+  int nx_start = 0, nx_n = 0;
+  auto fetch = [&](int64_t kk) {
+    nx_tile = (CLS < 0) ? kk : (int64_t)tile_order[kk];
+    nx_start = offsets[nx_tile];
+    const int e = (nx_tile + 1 < n_tiles) ? offsets[nx_tile + 1] : (int)n_isects;
+    nx_n = e - nx_start;
+    if (nx_n <= CAP) {
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) {
+        const int i = threadIdx.x + j * THREADS;
+        if (i < nx_n) pre[j] = pairs[nx_start + i];
+      }
+    }
+  };
+  if (k < k_end) fetch(k);
   for (; k < k_end; k += gridDim.x) {
-    const int64_t tile = (CLS < 0) ? k : (int64_t)tile_order[k];
-    const int start = offsets[tile];
-    const int end = (tile + 1 < n_tiles) ? offsets[tile + 1] : (int)n_isects;
-    const int n = end - start;
+    const int64_t tile = nx_tile;
+    const int start = nx_start, n = nx_n;
+    if (n > 0 && n <= CAP) {
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) {
+        const int i = threadIdx.x + j * THREADS;
+        if (i < n) buf_a[i] = pre[j];
+      }
+    }
+    __syncthreads();
+    if (k + gridDim.x < k_end) fetch(k + gridDim.x);
     if (n <= 0) continue;
     const int64_t cam = tile / T, tl = tile - cam * T;
     const int64_t key_hi = (cam << (32 + tile_n_bits)) | (tl << 32);
     if (n <= CAP) {
-      for (int i = threadIdx.x; i < n; i += THREADS) buf_a[i] = pairs[start + i];
-      __syncthreads();
       const uint2* cur = ts_sort<WAVES, uint16_t, true>(buf_a, buf_b, rank_s, n, sh);
       for (int i = threadIdx.x; i < n; i += THREADS) {
         const uint2 e = cur[i];
