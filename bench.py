@@ -34,22 +34,37 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 
 def algorithmic_bytes(N, C, H, W, K, D, V, I, absgrad=True, aa=True):
-    """SURVEY.md section 8(d) per-stage algorithmic HBM bytes for one step (fp32)."""
+    """SURVEY.md section 8(d) per-stage algorithmic HBM bytes for one step (fp32), keyed by the entry point that does
+    the stage's work here.  gsplat's isect_tiles + sort + offset_encode stages are the binned pipeline's four kernels:
+    `isect` (V*16 + I*12) is split over count (the V*16 box reads) and scatter (the I*12 pair writes), `sort` (I*24) is
+    the per-tile sort, `offsets` (I*8 + T*4) the offsets kernel."""
     P = C * H * W
     T = C * ((H + 15) // 16) * ((W + 15) // 16)
     b = {}
     b["gs_projection_fwd"] = N * (12 + 12 * K) + V * 12 + N * 40 + C * N * 4 + V * (24 + (4 if aa else 0))
-    b["gs_isect_count_visible"] = C * N * 8
-    b["gs_isect_depth_keys"] = C * N * 8 + V * 16
-    b["gs_radix_sort_pairs_u64_u32[depth]"] = V * 24
-    b["gs_isect_scan_ordered"] = V * 12
-    b["gs_isect_emit_ordered"] = V * 16 + I * 12
-    b["gs_radix_sort_pairs_u64_u32[tile]"] = I * 24
-    b["gs_isect_offset_encode"] = I * 8 + T * 4
+    b["gs_isect_bin_count"] = V * 16
+    b["gs_isect_bin_scatter"] = I * 12
+    b["gs_isect_tile_sort"] = I * 24
+    b["gs_isect_bin_offsets"] = I * 8 + T * 4
     b["gs_rasterize_fwd"] = I * (28 + 4 * D) + P * (4 * D + 8)
     b["gs_rasterize_bwd"] = I * (28 + 4 * D) + P * (4 * D + 12) + V * (4 * D + 12 + 8 + 4 + (8 if absgrad else 0))
     b["gs_projection_bwd"] = V * (24 + (4 if aa else 0)) + N * 40 + C * N * 4 + N * 40 + V * 12 + N * 12 + N * 12 * K
     return b
+
+
+def measured_traffic(kernel, N, C, H, W):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.py writes the
+    file; FETCH_SIZE and WRITE_SIZE need separate passes, so they cannot be collected inside this run)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if [t.get("gaussians"), t.get("cams"), t.get("height"), t.get("width")] != [N, C, H, W]:
+        return None
+    k = t.get("kernels", {}).get(kernel)
+    return int(k["hbm_bytes_per_launch"]) if k else None
 
 
 def cpu_baseline(threads: int):
@@ -178,7 +193,7 @@ def main():
             per_launch_ms = kern[dom][1]
             ach = bytes_[dom] / (per_launch_ms * 1e-3) / 1e9
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": measured_traffic(dom, N, C, H, W),
                         "algorithmic_bytes_per_launch": bytes_[dom], "avg_launch_ms": round(per_launch_ms, 4)}
         total_bytes = sum(bytes_.values())
         out = {

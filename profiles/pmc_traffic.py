@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Turns two rocprofv3 PMC passes over bench.py (one with FETCH_SIZE, one with WRITE_SIZE) into profiles/traffic.json,
+the per-launch HBM bytes bench.py reports as roofline.traffic.
+
+    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_rd -o p --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline
+    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_wr -o p --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline
+    python profiles/pmc_traffic.py gpurun_out/pmc_rd gpurun_out/pmc_wr > profiles/traffic.json
+
+Units and corrections (/opt/skills/guides/MI355X_MICROARCH.md, "HBM"): both counters are in KiB; on gfx950 FETCH_SIZE
+tallies each 128-B fabric read request as 64 B, so wide coalesced reads show exactly half their bytes -> doubled here;
+WRITE_SIZE is exact for streaming stores and float atomics.  The x2 read correction is checked in the same pass against a
+kernel of known byte count (rocBLAS dot over the loss weights: 2 x 4 x C*H*W*D bytes) and the write unit against the
+torch fill of the gradient record (C*N*64 bytes); both ratios are printed into the JSON as `calibration`.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+KERNELS = {  # bench.py entry-point label -> substring(s) of the HIP kernel names it launches
+    "gs_projection_fwd": ["gs::projection_fwd_kernel"],
+    "gs_projection_bwd": ["gs::projection_bwd_kernel"],
+    "gs_isect_bin_count": ["gs::isect_bin_kernel<false>"],
+    "gs_isect_bin_scatter": ["gs::isect_bin_kernel<true>"],
+    "gs_isect_bin_offsets": ["gs::bin_slice_prefix_kernel", "gs::bin_offsets_kernel"],
+    "gs_isect_tile_sort": ["gs::tile_sort_kernel"],
+    "gs_rasterize_fwd": ["gs::rasterize_fwd_kernel"],
+    "gs_rasterize_bwd": ["gs::rasterize_bwd_kernel"],
+}
+
+
+def per_kernel(directory, counter):
+    """{kernel name: (launches, mean counter value per launch)} from every counter_collection csv under directory."""
+    tot, cnt = defaultdict(float), defaultdict(int)
+    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                if row["Counter_Name"] != counter:
+                    continue
+                tot[row["Kernel_Name"]] += float(row["Counter_Value"])
+                cnt[row["Kernel_Name"]] += 1
+    return {k: (cnt[k], tot[k] / cnt[k]) for k in tot}
+
+
+def main():
+    rd_dir, wr_dir = sys.argv[1], sys.argv[2]
+    N, C, H, W, D = 1_000_000, 5, 375, 1242, 4
+    rd = per_kernel(rd_dir, "FETCH_SIZE")
+    wr = per_kernel(wr_dir, "WRITE_SIZE")
+    out = {"gaussians": N, "cams": C, "height": H, "width": W,
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py, mean per launch; "
+                     "FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count correction), WRITE_SIZE KiB x 1024",
+           "kernels": {}, "calibration": {}}
+    for label, subs in KERNELS.items():
+        fetch = sum(v[1] for k, v in rd.items() if any(s in k for s in subs))
+        write = sum(v[1] for k, v in wr.items() if any(s in k for s in subs))
+        launches = max([v[0] for k, v in rd.items() if any(s in k for s in subs)] or [0])
+        out["kernels"][label] = {
+            "fetch_size_kib_raw": round(fetch, 1), "write_size_kib_raw": round(write, 1),
+            "read_bytes_per_launch": int(fetch * 1024 * 2), "write_bytes_per_launch": int(write * 1024),
+            "hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024), "launches_seen": launches,
+        }
+    for k, v in rd.items():
+        if "rocblas_dot_kernel" in k:  # reads two [C,H,W,D] / [C,H,W,1] fp32 vectors per call, alternately
+            expect = (2 * 4 * C * H * W * D + 2 * 4 * C * H * W) / 2
+            out["calibration"]["read: rocblas dot, corrected/expected"] = round(v[1] * 2048 / expect, 3)
+    for k, v in wr.items():
+        if "FillFunctor<float>" in k:
+            out["calibration"]["write: torch fill mean KiB per launch (raw)"] = round(v[1], 1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
