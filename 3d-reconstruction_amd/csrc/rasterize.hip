@@ -1,16 +1,24 @@
 // rasterize_to_pixels forward / backward for gfx950 (the reference reaches
 // it through /root/reference/3D-Reconstruction-main/models/trainers/base.py:393-408).
 //
-// MI355X-first decomposition: ONE WAVE64 PER 16x16 TILE, FOUR PIXELS (a 2x2 quad) PER LANE.
+// MI355X-first decomposition: ONE WAVE64 PER 16x16 TILE, FOUR PIXELS (a 2x2 quad) PER LANE, and the wave's four
+// DPP rows (16 lanes each) own the tile's four 8x8 QUADRANTS.
 //   * a tile's sorted Gaussian list is staged through LDS in batches of 64 splat records (each lane
 //     gathers one 64-B record = one HBM request, next batch prefetched into VGPRs behind the current one);
-//   * every broadcast LDS read of a record is amortised over 4 pixels per lane (a 16x16-thread block would
+//   * at staging ONE lane per splat culls it exactly against each quadrant, and every quadrant gets its own
+//     order-preserving queue of LDS record offsets: in one inner-loop iteration the four rows composite FOUR
+//     DIFFERENT splats, so a splat that touches one corner of the tile costs a quarter of a wave-iteration, and
+//     a quadrant whose 64 pixels have all terminated stops taking splats (early termination per 8x8 block);
+//   * every LDS read of a record is amortised over 4 pixels per lane (a 16x16-thread block would
 //     issue 4x the LDS reads per pixel-Gaussian and be LDS-issue-bound on CDNA4's 256 B/clk LDS);
 //   * a workgroup is a single wave: no cross-wave barrier anywhere in the inner loops, early termination
 //     is one 64-bit ballot, and a tile's wave retires independently of its neighbours;
-//   * backward: each lane first sums its 4 pixels' contributions in registers, then the wave does a
-//     12-value reduce-scatter (v_permlane32_swap, v_permlane16_swap, DPP row mirrors) in 28 VALU ops and
-//     12 lanes issue ONE atomic instruction covering one contiguous 48-B gradient record.
+//   * backward: one splat per wave-iteration (whole-tile cull).  Each lane first sums its 4 pixels' contributions
+//     in registers, then the wave does a 12-value reduce-scatter (v_permlane32_swap, v_permlane16_swap, DPP row
+//     mirrors) in 28 VALU ops and 12 lanes issue ONE atomic instruction covering one contiguous 48-B gradient
+//     record.  Quadrant queues were measured here too and lose: four rows adding the SAME splat's record within a
+//     microsecond of each other serialise at the memory-side atomic units (0.47 -> 0.71 ms), and merging them in
+//     LDS first (ds_add_f32 + a per-batch flush) costs what the shorter walk saves (0.49 ms).
 // No MFMA: nothing here is a dense contraction.  The forward is VALU/transcendental-issue bound, the
 // backward VALU + atomic bound; HBM traffic is the 48-B-per-intersection gather + the image.
 #include "gs_common.hpp"
@@ -56,16 +64,17 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr float CONIC_SCALE = -0.5f * LOG2E;
 
-// Exact (conservative) per-tile cull, done by ONE lane per splat at staging time: an upper bound of pw over the
-// tile's 16x16 pixel-centre rectangle [x0, x0+15] x [y0, y0+15].  pw is a negative-definite quadratic with its
-// maximum (0) at the mean, so the constrained maximum lies on a face nearest the mean: maximise the 1-D
-// quadratic on the face dx = clamp(0) and on the face dy = clamp(0) and take the larger.  A splat whose best
-// possible alpha in the tile is below 1/255 is skipped by every pixel anyway (A.5: `alpha < 1/255 -> continue`),
-// so dropping it here changes no output bit; `slack` covers the fp32 rounding of the per-pixel evaluation.
-__device__ __forceinline__ bool tile_may_touch(float mx, float my, float A, float Bh, float C, float opac, float x0,
-                                               float y0) {
-  const float dxh = mx - x0, dxl = dxh - 15.f;
-  const float dyh = my - y0, dyl = dyh - 15.f;
+// Exact (conservative) cull, done by ONE lane per splat at staging time: an upper bound of pw over the pixel-centre
+// rectangle [x0, x0+ext] x [y0, y0+ext] (ext = 7: one 8x8 quadrant, forward; ext = 15: the whole tile, backward).
+// pw is a negative-definite quadratic with its maximum (0) at the mean, so the constrained maximum lies on a face
+// nearest the mean: maximise the 1-D quadratic on the face dx = clamp(0) and on the face dy = clamp(0) and take the
+// larger.  A splat whose best possible alpha in the rectangle is below 1/255 is skipped by every pixel of it anyway
+// (A.5: `alpha < 1/255 -> continue`), so dropping it here changes no output bit; `slack` covers the fp32 rounding
+// of the per-pixel evaluation.
+__device__ __forceinline__ bool rect_may_touch(float mx, float my, float A, float Bh, float C, float opac, float x0,
+                                               float y0, float ext) {
+  const float dxh = mx - x0, dxl = dxh - ext;
+  const float dyh = my - y0, dyl = dyh - ext;
   const float cx = fminf(fmaxf(0.f, dxl), dxh);
   const float cy = fminf(fmaxf(0.f, dyl), dyh);
   const float ys = fminf(fmaxf(-Bh * cx * __builtin_amdgcn_rcpf(C), dyl), dyh);
@@ -79,6 +88,57 @@ __device__ __forceinline__ bool tile_may_touch(float mx, float my, float A, floa
   return !(opac * __builtin_amdgcn_exp2f(pmax) < ALPHA_MIN * 0.999f);
 }
 
+// ------------------------------------------------------------------------------------------ quadrant queues
+// LDS image of one staged batch: 64 record slots + one NULL record (all zero: opacity 0 -> alpha 0, never used by a
+// pixel) and, per quadrant, a queue of u16 byte offsets into the record area in list order, padded with the NULL
+// record's offset up to the longest queue of the batch (the inner loop reads one entry ahead, hence the fixed tail).
+constexpr int Q_SLOTS = 65;
+constexpr int Q_REC_BYTES = 48;
+constexpr int Q_NULL_OFF = 64 * Q_REC_BYTES;
+constexpr int Q_STRIDE = 68;  // u16 entries per queue: 64 + a NULL tail
+
+__device__ __forceinline__ void stage_init(float4* __restrict__ sg, unsigned short* __restrict__ qidx, int lane) {
+  // {mean 0, conic 0} {C 0, opacity 0, colour 0} {colour 0, list index 0, gradient row -1 (bits, never a float)}
+  if (lane < 3) sg[64 * 3 + lane] = make_float4(0.f, 0.f, 0.f, lane == 2 ? __int_as_float(-1) : 0.f);
+  if (lane < 16) qidx[(lane >> 2) * Q_STRIDE + 64 + (lane & 3)] = (unsigned short)Q_NULL_OFF;
+}
+
+// One lane per staged list entry: scale the conic, cull the splat exactly against each quadrant it is offered to
+// (`qmask` bit q; 0 for lanes past the end of the list), write the record, append its offset to the queues of the
+// quadrants it may touch (ballot compaction, list order preserved).  Returns the longest queue's length.
+__device__ __forceinline__ int stage_batch(float4* __restrict__ sg, unsigned short* __restrict__ qidx, int lane,
+                                           unsigned qmask, float4 n0, float4 n1, float4 rec2, float x0, float y0) {
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const float A = CONIC_SCALE * n0.z, Bh = CONIC_SCALE * n0.w, Cc = CONIC_SCALE * n1.x;
+  int cnt[4];
+  int nmax = 0;
+  bool any = false;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool m = ((qmask >> q) & 1u) &&
+                   rect_may_touch(n0.x, n0.y, A, Bh, Cc, n1.y, x0 + 8.f * (float)(q & 1), y0 + 8.f * (float)(q >> 1), 7.f);
+    const unsigned long long bal = __ballot(m);
+    cnt[q] = __popcll(bal);
+    if (m) qidx[q * Q_STRIDE + __popcll(bal & lt_mask)] = (unsigned short)(lane * Q_REC_BYTES);
+    any |= m;
+    nmax = max(nmax, cnt[q]);
+  }
+  if (any) {
+    sg[lane * 3 + 0] = make_float4(n0.x, n0.y, A, Bh);
+    sg[lane * 3 + 1] = make_float4(Cc, n1.y, n1.z, n1.w);
+    sg[lane * 3 + 2] = rec2;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (lane >= cnt[q] && lane <= nmax) qidx[q * Q_STRIDE + lane] = (unsigned short)Q_NULL_OFF;
+  return nmax;
+}
+
+__device__ __forceinline__ unsigned quadrants_of(unsigned long long lanes) {  // bit q: some lane of row q is set
+  return ((lanes & 0xFFFFull) ? 1u : 0u) | ((lanes & 0xFFFF0000ull) ? 2u : 0u) |
+         ((lanes & 0xFFFF00000000ull) ? 4u : 0u) | ((lanes & 0xFFFF000000000000ull) ? 8u : 0u);
+}
+
 // ------------------------------------------------------------------------------------------ forward
 template <int CH>
 __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
@@ -86,7 +146,8 @@ __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
     const int32_t* __restrict__ flatten_ids, int64_t n_isects, const float* __restrict__ backgrounds, int ed,
     float* __restrict__ out_c, float* __restrict__ out_a, int32_t* __restrict__ last_ids,
     const int32_t* __restrict__ tile_order, int32_t* __restrict__ tile_work) {
-  __shared__ float4 sg[64 * 3];
+  __shared__ float4 sg[Q_SLOTS * 3];
+  __shared__ unsigned short qidx[4 * Q_STRIDE];
   const unsigned n_tiles = (unsigned)(C * TW * TH);
   unsigned tile;
   if (tile_order) {
@@ -98,9 +159,9 @@ __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
   }
   const TileGeom tg = tile_geom(tile, TW, TH, n_tiles, offsets, n_isects);
   const int lane = threadIdx.x;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const int quad = lane >> 4, rl = lane & 15;  // DPP row = quadrant; 4x4 lanes of 2x2 pixels inside it
   const float x0 = (float)(tg.tx * 16) + 0.5f, y0 = (float)(tg.ty * 16) + 0.5f;
-  const int ix0 = tg.tx * 16 + 2 * (lane & 7), iy0 = tg.ty * 16 + 2 * (lane >> 3);
+  const int ix0 = tg.tx * 16 + 8 * (quad & 1) + 2 * (rl & 3), iy0 = tg.ty * 16 + 8 * (quad >> 1) + 2 * (rl >> 2);
   const float px0 = (float)ix0 + 0.5f, py0 = (float)iy0 + 0.5f;
   // T > 0: pixel live.  T < 0: pixel stopped (or outside the image); |T| is its final transmittance.
   float T[4], acc[4][CH];
@@ -113,6 +174,7 @@ __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
 #pragma unroll
     for (int k = 0; k < CH; ++k) acc[p][k] = 0.f;
   }
+  stage_init(sg, qidx, lane);
 
   const int nbatch = (tg.end - tg.start + 63) >> 6;
   float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
@@ -124,25 +186,22 @@ __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
     }
   };
   if (nbatch > 0) prefetch(0);
-  bool all_done = __ballot(T[0] > 0.f || T[1] > 0.f || T[2] > 0.f || T[3] > 0.f) == 0ull;
-  for (int b = 0; b < nbatch && !all_done; ++b) {
+  unsigned long long live = __ballot(T[0] > 0.f || T[1] > 0.f || T[2] > 0.f || T[3] > 0.f);
+  const unsigned short* myq = qidx + quad * Q_STRIDE;
+  for (int b = 0; b < nbatch && live != 0ull; ++b) {
     const int kbase = tg.start + b * 64;
-    // stage: scale the conic, cull against the tile rectangle, compact (order preserved)
-    const float A = CONIC_SCALE * n0.z, Bh = CONIC_SCALE * n0.w, Cc = CONIC_SCALE * n1.x;
-    const bool keep = (kbase + lane < tg.end) && tile_may_touch(n0.x, n0.y, A, Bh, Cc, n1.y, x0, y0);
-    const unsigned long long kmask = __ballot(keep);
-    const int cnt = __popcll(kmask);
-    if (keep) {
-      const int pos = __popcll(kmask & lt_mask);
-      sg[pos * 3 + 0] = make_float4(n0.x, n0.y, A, Bh);
-      sg[pos * 3 + 1] = make_float4(Cc, n1.y, n1.z, n1.w);
-      sg[pos * 3 + 2] = make_float4(n2.x, n2.y, __int_as_float(kbase + lane), 0.f);
-    }
+    // a quadrant whose pixels have all stopped takes no more splats
+    const unsigned qmask = (kbase + lane < tg.end) ? quadrants_of(live) : 0u;
+    const int nmax = stage_batch(sg, qidx, lane, qmask, n0, n1,
+                                 make_float4(n2.x, n2.y, __int_as_float(kbase + lane), 0.f), x0, y0);
     __syncthreads();
     if (b + 1 < nbatch) prefetch(b + 1);
-    for (int j = 0; j < cnt; ++j) {
-      const float4 q0 = sg[j * 3 + 0];
-      const float4 q1 = sg[j * 3 + 1];
+    unsigned off = myq[0];
+    for (int j = 0; j < nmax; ++j) {
+      const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sg) + off);
+      off = myq[j + 1];
+      const float4 q0 = rec[0];
+      const float4 q1 = rec[1];
       const float dx0 = q0.x - px0, dx1 = dx0 - 1.f;
       const float dy0 = q0.y - py0, dy1 = dy0 - 1.f;
       const float adx[2] = {q0.z * dx0, q0.z * dx1}, bdx[2] = {q0.w * dx0, q0.w * dx1};
@@ -160,7 +219,7 @@ __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
         any_use |= use[p];
       }
       if (__ballot(any_use) == 0ull) continue;
-      const float4 q2 = sg[j * 3 + 2];
+      const float4 q2 = rec[2];
       const float col[4] = {q1.z, q1.w, q2.x, q2.y};
       const int kcur = __float_as_int(q2.z);
       bool any_stop = false;
@@ -177,7 +236,8 @@ __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
         T[p] = go ? nT : (stop ? -T[p] : T[p]);
       }
       if (__ballot(any_stop) != 0ull) {
-        if (__ballot(T[0] > 0.f || T[1] > 0.f || T[2] > 0.f || T[3] > 0.f) == 0ull) { all_done = true; break; }
+        live = __ballot(T[0] > 0.f || T[1] > 0.f || T[2] > 0.f || T[3] > 0.f);
+        if (live == 0ull) break;
       }
     }
     __syncthreads();
@@ -357,7 +417,7 @@ __global__ __launch_bounds__(64) void rasterize_bwd_kernel(
   if (k_top >= tg.start) prefetch(k_top);
   for (int kb = k_top; kb >= tg.start; kb -= 64) {
     const float A = CONIC_SCALE * n0.z, Bh = CONIC_SCALE * n0.w, Cc = CONIC_SCALE * n1.x;
-    const bool keep = (kb - lane >= tg.start) && tile_may_touch(n0.x, n0.y, A, Bh, Cc, n1.y, x0, y0);
+    const bool keep = (kb - lane >= tg.start) && rect_may_touch(n0.x, n0.y, A, Bh, Cc, n1.y, x0, y0, 15.f);
     const unsigned long long kmask = __ballot(keep);
     const int cnt = __popcll(kmask);
     if (keep) {

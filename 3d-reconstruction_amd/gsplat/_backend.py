@@ -69,7 +69,8 @@ _lib: Optional[ctypes.CDLL] = None
 
 
 def lib_path() -> str:
-    return os.path.normpath(_LIB_PATH)
+    """In-tree build output; GSPLAT_MI355X_LIB points at another build of the same ABI (kernel A/B experiments)."""
+    return os.path.normpath(os.environ.get("GSPLAT_MI355X_LIB") or _LIB_PATH)
 
 
 def lib() -> ctypes.CDLL:

@@ -68,6 +68,46 @@ __global__ __launch_bounds__(64) void k(float* out, long long* cyc, int iters) {
 #define X(i) asm volatile("v_cmp_le_f32 vcc, %0, %1" :: "v"(s[i]), "v"(bs) : "vcc");
       REP8(X) REP8(X)
 #undef X
+    } else if constexpr (MODE == 10) {
+#define X(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(s[i]) : "v"(bs) : "s20", "s21");
+      REP8(X) REP8(X)
+#undef X
+    } else if constexpr (MODE == 11) {
+#define X(i) asm volatile("v_cmp_le_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(s[i]) : "v"(bs) : "vcc");
+      REP8(X)
+#undef X
+    } else if constexpr (MODE == 12) {
+#define X(i) asm volatile("v_max_f32 %0, %0, %1" : "+v"(s[i]) : "v"(bs));
+      REP8(X) REP8(X)
+#undef X
+    } else if constexpr (MODE == 13) {
+#define X(i) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(s[i]) : "v"(bs), "v"(cs));
+      REP8(X) REP8(X)
+#undef X
+    } else if constexpr (MODE == 14) {
+#define X(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(s[i]) : "v"(bs));
+      REP8(X) REP8(X)
+#undef X
+    } else if constexpr (MODE == 15) {
+#define X(i) asm volatile("v_cmp_le_f32 s[20:21], %0, %1" :: "v"(s[i]), "v"(bs) : "s20", "s21");
+      REP8(X) REP8(X)
+#undef X
+    } else if constexpr (MODE == 16) {
+#define X(i) asm volatile("v_mov_b32 %0, %1" : "=v"(s[i]) : "v"(bs));
+      REP8(X) REP8(X)
+#undef X
+    } else if constexpr (MODE == 17) {
+#define X(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(s[i]) : "v"(bs));
+      REP8(X) REP8(X)
+#undef X
+    } else if constexpr (MODE == 18) {
+#define X(i) asm volatile("v_fma_f32 %0, %0, %1, |%0|" : "+v"(s[i]) : "v"(bs));
+      REP8(X) REP8(X)
+#undef X
+    } else if constexpr (MODE == 19) {
+#define X(i) asm volatile("v_add_f32 %0, s20, %0" : "+v"(s[i]) :: "s20");
+      REP8(X) REP8(X)
+#undef X
     }
   }
   long long t1 = __builtin_amdgcn_s_memtime();
@@ -115,5 +155,15 @@ int main() {
   run<5>("v_permlane32_swap");
   run<7>("v_cndmask_b32");
   run<9>("v_cmp_le_f32");
+  run<10>("v_cndmask sgpr mask");
+  run<11>("cmp+cndmask pair(x8)");
+  run<12>("v_max_f32");
+  run<13>("v_cndmask nondep");
+  run<14>("v_mul_f32");
+  run<15>("v_cmp -> sgpr");
+  run<16>("v_mov_b32");
+  run<17>("v_add_f32");
+  run<18>("v_fma_f32 abs mod");
+  run<19>("v_add_f32 sgpr src");
   return 0;
 }
