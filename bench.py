@@ -69,7 +69,7 @@ def measured_traffic(kernel, N, C, H, W):
 
 def cpu_baseline(threads: int):
     """BASELINE.json configs[0]: the oracle (pure-PyTorch restatement of gsplat's algorithm) on host cores,
-    100k Gaussians, SH degree 3, one 1242x375 camera, one fwd+bwd (~10-20 s of CPU work)."""
+    100k Gaussians, SH degree 3, one 1242x375 camera, a few fwd+bwd steps (~12-20 s of CPU work)."""
     import oracle
 
     torch.set_num_threads(threads)
@@ -81,15 +81,22 @@ def cpu_baseline(threads: int):
     gen = torch.Generator().manual_seed(1)
     wc = torch.randn(1, H, W, 4, generator=gen)
     wa = torch.randn(1, H, W, 1, generator=gen)
-    t0 = time.perf_counter()
-    rc, ra, _ = oracle.rasterization(g["means"], g["quats"], g["scales"], g["opacities"], g["colors"], vm, Ks, W, H,
-                                     near_plane=0.1, sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased")
-    ((rc * wc).sum() + (ra * wa).sum()).backward()
-    dt = time.perf_counter() - t0
+    reps, t_all = 0, 0.0
+    while reps < 8 and (reps < 2 or t_all < 12.0):  # a bounded sample: at least ~12 s of CPU work, at most 8 steps
+        for v in g.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        rc, ra, _ = oracle.rasterization(g["means"], g["quats"], g["scales"], g["opacities"], g["colors"], vm, Ks, W, H,
+                                         near_plane=0.1, sh_degree=3, render_mode="RGB+ED",
+                                         rasterize_mode="antialiased")
+        ((rc * wc).sum() + (ra * wa).sum()).backward()
+        t_all += time.perf_counter() - t0
+        reps += 1
+    dt = t_all / reps
     return {
         "value": round(W * H / dt / 1e6, 5), "unit": "Mpix/s", "cores": threads, "kind": "port",
-        "sample": f"configs[0]: 100k Gaussians, SH deg 3, one 1242x375 camera, 1 fwd+bwd in {dt:.1f} s (fp32, "
-                  f"torch CPU, {threads} threads)",
+        "sample": f"configs[0]: 100k Gaussians, SH deg 3, one 1242x375 camera, {reps} fwd+bwd steps, mean {dt:.2f} s "
+                  f"each (fp32, torch CPU, {threads} threads)",
     }
 
 
