@@ -478,8 +478,13 @@ __global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(int32_t T, int32_
                                                                const int32_t* __restrict__ offsets, int64_t n_isects,
                                                                const int32_t* __restrict__ tile_order,
                                                                const int32_t* __restrict__ size_classes, uint2* pairs,
-                                                               int64_t* isect_ids, int32_t* flatten_ids) {
+                                                               int64_t* isect_ids, int32_t* flatten_ids,
+                                                               const int32_t* sel, int32_t sel_mode,
+                                                               int32_t* sorted_cnt) {
+  // sel != NULL restricts the launch to the tiles with sel[tile] < 0 (sel_mode 0: segments the front sort deferred)
+  // or sel[tile] != 0 (sel_mode 1: tiles the rasterizer flagged); sorted_cnt[tile] = n marks a segment fully sorted
   constexpr int THREADS = WAVES * 64;
+  if (sel && sel_mode == 1 && sel[n_tiles] == 0) return;  // redo launch with no flagged tile (the usual case)
   __shared__ uint2 buf_a[CAP];
   __shared__ uint2 buf_b[CAP];
   __shared__ uint16_t rank_s[CAP];
@@ -500,6 +505,7 @@ __global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(int32_t T, int32_
     nx_start = offsets[nx_tile];
     const int e = (nx_tile + 1 < n_tiles) ? offsets[nx_tile + 1] : (int)n_isects;
     nx_n = e - nx_start;
+    if (sel && !(sel_mode == 0 ? sel[nx_tile] < 0 : sel[nx_tile] != 0)) nx_n = 0;
     if (nx_n <= CAP) {
 #pragma unroll
       for (int j = 0; j < ITEMS; ++j) {
@@ -545,6 +551,144 @@ __global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(int32_t T, int32_
         flatten_ids[start + i] = (int32_t)e.y;
       }
     }
+    if (sorted_cnt && threadIdx.x == 0) sorted_cnt[tile] = n;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------ front sort
+// The compositor stops a tile once every pixel's transmittance falls under 1e-4; on dense scenes that is a few
+// hundred entries into a list of thousands (BASELINE configs[4] shape: 7 % of the entries are ever read).  For a
+// long segment, sort only its FRONT: histogram the depths into 512 linear buckets (streaming, the segment never has
+// to fit in LDS), take the leading buckets that hold at least k_target entries, counting-sort exactly those entries
+// into LDS, order every bucket on the 64-bit (depth, id) key and write them out.  The result is the first nf
+// entries of the full A.3 order (buckets are depth-monotone, equal depths share a bucket); sorted_cnt[tile] = nf.
+// The tail stays unsorted in `pairs` until someone needs it: the rasterizer flags a tile whose pixels are still
+// live at the end of the front (gs_isect_tile_sort_redo sorts it fully and the tile is rasterized again), and
+// gs_isect_tile_sort completes every tile when the caller asks for the isect_ids / flatten_ids arrays.
+// A front that does not fit the LDS buffer or has a crowded bucket is deferred (sorted_cnt = -1) to the full sort.
+constexpr int TSF_CAP = 2048;
+constexpr int TSF_MIN = 1024;  // segments up to this length are sorted whole by the class 2/3 launches
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void tile_sort_front_kernel(
+    int32_t T, int32_t tile_n_bits, int64_t n_tiles, const int32_t* __restrict__ offsets, int64_t n_isects,
+    const int32_t* __restrict__ tile_order, const int32_t* __restrict__ size_classes, int32_t k_target,
+    const uint2* __restrict__ pairs, int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids,
+    int32_t* __restrict__ sorted_cnt) {
+  constexpr int THREADS = WAVES * 64;
+  static_assert(THREADS == 256, "the scan below assigns two buckets to each of 256 threads");
+  __shared__ uint2 buf[TSF_CAP];
+  __shared__ uint32_t cnt[TS_MAX_RADIX];
+  __shared__ uint32_t bstart[TS_MAX_RADIX + 1];
+  __shared__ uint32_t red_min[WAVES], red_max[WAVES], wsum[WAVES];
+  __shared__ int s_bstar, s_bmax[WAVES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t k_end = size_classes[1];  // tiles with more than TSF_MIN entries lead the longest-first order
+  for (int64_t k = blockIdx.x; k < k_end; k += gridDim.x) {
+    const int64_t tile = tile_order[k];
+    const int start = offsets[tile];
+    const int e_end = (tile + 1 < n_tiles) ? offsets[tile + 1] : (int)n_isects;
+    const int n = e_end - start;
+    const uint2* seg = pairs + start;
+    // ---- depth range
+    uint32_t kmin = 0xffffffffu, kmax = 0u;
+    for (int i = tid; i < n; i += THREADS) {
+      const uint32_t kk = seg[i].x;
+      kmin = min(kmin, kk);
+      kmax = max(kmax, kk);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o));
+      kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o));
+    }
+    if (lane == 0) { red_min[wave] = kmin; red_max[wave] = kmax; }
+    cnt[tid] = 0; cnt[tid + THREADS] = 0;
+    if (tid == 0) s_bstar = -1;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) { kmin = min(kmin, red_min[w]); kmax = max(kmax, red_max[w]); }
+    const float dmin = __uint_as_float(kmin);
+    const float bscale = (kmax > kmin) ? (float)(TS_MAX_RADIX - 1) / (__uint_as_float(kmax) - dmin) : 0.f;
+    auto bucket = [&](uint32_t kk) -> int {
+      return min(TS_MAX_RADIX - 1, (int)((__uint_as_float(kk) - dmin) * bscale));
+    };
+    // ---- histogram, exclusive scan (two buckets per thread)
+    for (int i = tid; i < n; i += THREADS) atomicAdd(&cnt[bucket(seg[i].x)], 1u);
+    __syncthreads();
+    const uint32_t t0 = cnt[2 * tid], t1 = cnt[2 * tid + 1];
+    uint32_t incl = t0 + t1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - (t0 + t1);
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w)
+      if (w < wave) run += wsum[w];
+    bstart[2 * tid] = run;
+    bstart[2 * tid + 1] = run + t0;
+    if (tid == THREADS - 1) bstart[TS_MAX_RADIX] = (uint32_t)n;
+    // the bucket in which the running count reaches k_target closes the front
+    if (run < (uint32_t)k_target && run + t0 >= (uint32_t)k_target) s_bstar = 2 * tid;
+    else if (run + t0 < (uint32_t)k_target && run + t0 + t1 >= (uint32_t)k_target) s_bstar = 2 * tid + 1;
+    __syncthreads();
+    const int bstar = s_bstar;
+    const int nf = bstar >= 0 ? (int)bstart[bstar + 1] : n + TSF_CAP;
+    // crowded bucket inside the front?  (one lane orders a bucket by insertion)
+    int bmx = 0;
+    if (2 * tid <= bstar) bmx = (int)t0;
+    if (2 * tid + 1 <= bstar) bmx = max(bmx, (int)t1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bmx = max(bmx, __shfl_xor(bmx, o));
+    if (lane == 0) s_bmax[wave] = bmx;
+    __syncthreads();
+    bmx = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) bmx = max(bmx, s_bmax[w]);
+    if (nf > TSF_CAP || bmx > TS_BUCKET_MAX) {
+      if (tid == 0) sorted_cnt[tile] = -1;
+      __syncthreads();
+      continue;
+    }
+    // ---- counting placement of the front entries, then per-bucket insertion sort on (depth, id)
+    if (2 * tid <= bstar) cnt[2 * tid] = bstart[2 * tid];
+    if (2 * tid + 1 <= bstar) cnt[2 * tid + 1] = bstart[2 * tid + 1];
+    __syncthreads();
+    for (int i = tid; i < n; i += THREADS) {
+      const uint2 en = seg[i];
+      const int b = bucket(en.x);
+      if (b <= bstar) buf[atomicAdd(&cnt[b], 1u)] = en;
+    }
+    __syncthreads();
+    for (int d = tid; d <= bstar; d += THREADS) {
+      const int s0 = (int)bstart[d], s1 = (int)bstart[d + 1];
+      for (int j = s0 + 1; j < s1; ++j) {
+        const uint2 v = buf[j];
+        const unsigned long long kv = ts_key64(v);
+        int q = j - 1;
+        while (q >= s0) {
+          const uint2 pv = buf[q];
+          if (ts_key64(pv) <= kv) break;
+          buf[q + 1] = pv;
+          --q;
+        }
+        buf[q + 1] = v;
+      }
+    }
+    __syncthreads();
+    const int64_t cam = tile / T, tl = tile - cam * T;
+    const int64_t key_hi = (cam << (32 + tile_n_bits)) | (tl << 32);
+    for (int i = tid; i < nf; i += THREADS) {
+      const uint2 en = buf[i];
+      isect_ids[start + i] = key_hi | (int64_t)en.x;
+      flatten_ids[start + i] = (int32_t)en.y;
+    }
+    if (tid == 0) sorted_cnt[tile] = nf;
     __syncthreads();
   }
 }
@@ -627,7 +771,7 @@ extern "C" int gs_isect_tile_sort(int32_t C, int32_t tile_w, int32_t tile_h, con
   const int64_t n_tiles = (int64_t)C * T;
   hipStream_t s = (hipStream_t)stream;
   uint2* pr = reinterpret_cast<uint2*>(pairs);
-#define GS_TS_ARGS T, tile_n_bits, n_tiles, isect_offsets, n_isects, tile_order, size_classes, pr, isect_ids, flatten_ids
+#define GS_TS_ARGS T, tile_n_bits, n_tiles, isect_offsets, n_isects, tile_order, size_classes, pr, isect_ids, flatten_ids, (const int32_t*)nullptr, 0, (int32_t*)nullptr
   if (tile_order && size_classes) {
     // longest lists first; grids are persistent and sized to the LDS-limited residency of each class
     hipLaunchKernelGGL((gs::tile_sort_kernel<6144, 0, 16>), dim3(256), dim3(1024), 0, s, GS_TS_ARGS);
@@ -638,6 +782,70 @@ extern "C" int gs_isect_tile_sort(int32_t C, int32_t tile_w, int32_t tile_h, con
     hipLaunchKernelGGL((gs::tile_sort_kernel<2048, -1, 4>), dim3((unsigned)n_tiles), dim3(256), 0, s, GS_TS_ARGS);
   }
 #undef GS_TS_ARGS
+  GS_CHECK_LAUNCH();
+  return GS_OK;
+}
+
+static int tile_sort_geom(int32_t C, int32_t tile_w, int32_t tile_h, int64_t n_isects, int* T, int* tile_n_bits) {
+  if (C < 1 || tile_w < 1 || tile_h < 1 || n_isects < 0) return GS_ERR_INVALID_ARG;
+  if (n_isects >= ((int64_t)1 << 31)) return GS_ERR_UNSUPPORTED;
+  *T = tile_w * tile_h;
+  *tile_n_bits = gs::bin_ilog2_floor(*T) + 1;
+  if (32 + *tile_n_bits + gs::bin_ilog2_floor(C) + 1 > 64) return GS_ERR_UNSUPPORTED;
+  return GS_OK;
+}
+
+extern "C" int gs_isect_tile_sort_front(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets,
+                                        int64_t n_isects, const int32_t* tile_order, const int32_t* size_classes,
+                                        int32_t k_target, uint64_t* pairs, int64_t* isect_ids, int32_t* flatten_ids,
+                                        int32_t* sorted_counts, void* stream) {
+  int T, tile_n_bits;
+  int st = tile_sort_geom(C, tile_w, tile_h, n_isects, &T, &tile_n_bits);
+  if (st != GS_OK) return st;
+  if (n_isects == 0) return GS_OK;
+  if (!isect_offsets || !tile_order || !size_classes || !pairs || !isect_ids || !flatten_ids || !sorted_counts)
+    return GS_ERR_INVALID_ARG;
+  if (k_target < 1 || k_target > gs::TSF_MIN) return GS_ERR_INVALID_ARG;
+  const int64_t n_tiles = (int64_t)C * T;
+  hipStream_t s = (hipStream_t)stream;
+  uint2* pr = reinterpret_cast<uint2*>(pairs);
+  hipLaunchKernelGGL((gs::tile_sort_front_kernel<4>), dim3(256 * 6), dim3(256), 0, s, T, tile_n_bits, n_tiles,
+                     isect_offsets, n_isects, tile_order, size_classes, k_target, (const uint2*)pr, isect_ids,
+                     flatten_ids, sorted_counts);
+#define GS_TSF_ARGS T, tile_n_bits, n_tiles, isect_offsets, n_isects, tile_order, size_classes, pr, isect_ids, flatten_ids
+  // segments the front kernel deferred (sorted_counts < 0): whole-segment sort, as gs_isect_tile_sort does
+  hipLaunchKernelGGL((gs::tile_sort_kernel<6144, 0, 16>), dim3(256), dim3(1024), 0, s, GS_TSF_ARGS,
+                     (const int32_t*)sorted_counts, 0, sorted_counts);
+  hipLaunchKernelGGL((gs::tile_sort_kernel<2048, 1, 4>), dim3(256 * 3), dim3(256), 0, s, GS_TSF_ARGS,
+                     (const int32_t*)sorted_counts, 0, sorted_counts);
+  // short segments: sorted whole (sorted_counts was pre-filled with the list lengths by the caller)
+  hipLaunchKernelGGL((gs::tile_sort_kernel<1024, 2, 1>), dim3(256 * 8), dim3(64), 0, s, GS_TSF_ARGS,
+                     (const int32_t*)nullptr, 0, (int32_t*)nullptr);
+  hipLaunchKernelGGL((gs::tile_sort_kernel<512, 3, 1>), dim3(256 * 14), dim3(64), 0, s, GS_TSF_ARGS,
+                     (const int32_t*)nullptr, 0, (int32_t*)nullptr);
+  GS_CHECK_LAUNCH();
+  return GS_OK;
+}
+
+extern "C" int gs_isect_tile_sort_redo(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets,
+                                       int64_t n_isects, const int32_t* tile_order, const int32_t* size_classes,
+                                       const int32_t* redo_flags, uint64_t* pairs, int64_t* isect_ids,
+                                       int32_t* flatten_ids, int32_t* sorted_counts, void* stream) {
+  int T, tile_n_bits;
+  int st = tile_sort_geom(C, tile_w, tile_h, n_isects, &T, &tile_n_bits);
+  if (st != GS_OK) return st;
+  if (n_isects == 0) return GS_OK;
+  if (!isect_offsets || !tile_order || !size_classes || !redo_flags || !pairs || !isect_ids || !flatten_ids ||
+      !sorted_counts)
+    return GS_ERR_INVALID_ARG;
+  const int64_t n_tiles = (int64_t)C * T;
+  hipStream_t s = (hipStream_t)stream;
+  uint2* pr = reinterpret_cast<uint2*>(pairs);
+  hipLaunchKernelGGL((gs::tile_sort_kernel<6144, 0, 16>), dim3(256), dim3(1024), 0, s, GS_TSF_ARGS, redo_flags, 1,
+                     sorted_counts);
+  hipLaunchKernelGGL((gs::tile_sort_kernel<2048, 1, 4>), dim3(256 * 3), dim3(256), 0, s, GS_TSF_ARGS, redo_flags, 1,
+                     sorted_counts);
+#undef GS_TSF_ARGS
   GS_CHECK_LAUNCH();
   return GS_OK;
 }

@@ -145,7 +145,8 @@ __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
     int C, int W, int H, int TW, int TH, const float* __restrict__ splats, const int32_t* __restrict__ offsets,
     const int32_t* __restrict__ flatten_ids, int64_t n_isects, const float* __restrict__ backgrounds, int ed,
     float* __restrict__ out_c, float* __restrict__ out_a, int32_t* __restrict__ last_ids,
-    const int32_t* __restrict__ tile_order, int32_t* __restrict__ tile_work) {
+    const int32_t* __restrict__ tile_order, int32_t* __restrict__ tile_work,
+    const int32_t* __restrict__ sorted_cnt, int32_t* __restrict__ redo_flags, int redo_pass) {
   __shared__ float4 sg[Q_SLOTS * 3];
   __shared__ unsigned short qidx[4 * Q_STRIDE];
   const unsigned n_tiles = (unsigned)(C * TW * TH);
@@ -157,7 +158,18 @@ __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
     tile = raster_tile_of(blockIdx.x);
     if (tile >= n_tiles) return;
   }
-  const TileGeom tg = tile_geom(tile, TW, TH, n_tiles, offsets, n_isects);
+  // second pass: only the tiles whose sorted front ran out (redo_flags[n_tiles] counts them: usually none)
+  if (redo_pass && (redo_flags[n_tiles] == 0 || redo_flags[tile] == 0)) return;
+  TileGeom tg = tile_geom(tile, TW, TH, n_tiles, offsets, n_isects);
+  // front-sorted lists (gs_isect_tile_sort_front): only the first sorted_cnt[tile] entries are in order yet
+  bool truncated = false;
+  if (sorted_cnt && !redo_pass) {
+    const int sc = sorted_cnt[tile];
+    if (sc < tg.end - tg.start) {
+      tg.end = tg.start + max(sc, 0);
+      truncated = true;
+    }
+  }
   const int lane = threadIdx.x;
   const int quad = lane >> 4, rl = lane & 15;  // DPP row = quadrant; 4x4 lanes of 2x2 pixels inside it
   const float x0 = (float)(tg.tx * 16) + 0.5f, y0 = (float)(tg.ty * 16) + 0.5f;
@@ -243,6 +255,12 @@ __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
     __syncthreads();
   }
 
+  // pixels still live where the sorted front ends: the tile needs its whole list (sorted by gs_isect_tile_sort_redo)
+  // and is rasterized again by the redo pass, which overwrites everything written below
+  if (truncated && live != 0ull && lane == 0) {
+    redo_flags[tile] = 1;
+    atomicAdd(&redo_flags[n_tiles], 1);
+  }
   if (tile_work) {
     // list entries the backward will walk for this tile (it starts at the wave's largest last id)
     int wmax = max(max(cur[0], cur[1]), max(cur[2], cur[3]));
@@ -583,17 +601,19 @@ static int raster_check(int32_t C, int32_t width, int32_t height, int32_t tile_s
   return GS_OK;
 }
 
-#define GS_RF_ARGS C, width, height, TW, TH, splats, isect_offsets, flatten_ids, n_isects, backgrounds, ed_last_channel, render_colors, render_alphas, last_ids, tile_order, tile_work
+#define GS_RF_ARGS C, width, height, TW, TH, splats, isect_offsets, flatten_ids, n_isects, backgrounds, ed_last_channel, render_colors, render_alphas, last_ids, tile_order, tile_work, sorted_counts, redo_flags, redo_pass
 #define GS_RF_LAUNCH(CHN) hipLaunchKernelGGL((gs::rasterize_fwd_kernel<CHN>), grid, block, 0, s, GS_RF_ARGS)
 
 extern "C" int gs_rasterize_fwd(int32_t C, int32_t width, int32_t height, int32_t tile_size, int32_t channels,
                                 const float* splats, const int32_t* isect_offsets, const int32_t* flatten_ids,
                                 int64_t n_isects, const float* backgrounds, int32_t ed_last_channel,
                                 float* render_colors, float* render_alphas, int32_t* last_ids,
-                                const int32_t* tile_order, int32_t* tile_work, void* stream) {
+                                const int32_t* tile_order, int32_t* tile_work, const int32_t* sorted_counts,
+                                int32_t* redo_flags, int32_t redo_pass, void* stream) {
   int st = raster_check(C, width, height, tile_size, channels, n_isects);
   if (st != GS_OK) return st;
   if (!isect_offsets || !render_colors || !render_alphas || !last_ids) return GS_ERR_INVALID_ARG;
+  if ((sorted_counts || redo_pass) && !redo_flags) return GS_ERR_INVALID_ARG;
   if (n_isects > 0 && (!splats || !flatten_ids)) return GS_ERR_INVALID_ARG;
   const int TW = (width + 15) / 16, TH = (height + 15) / 16;
   hipStream_t s = (hipStream_t)stream;

@@ -56,7 +56,9 @@ _SIGNATURES = {
     "gs_radix_sort_pairs_u64_u32_bits": (ctypes.c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, c_int64, POINTER(c_int32), _P]),
     "gs_radix_sort_pairs_u64_u32": (ctypes.c_int, [c_int64, c_int32, _P, _P, _P, _P, _P, c_int64, POINTER(c_int32), _P]),
     "gs_isect_offset_encode": (ctypes.c_int, [c_int64, _P, c_int32, c_int32, c_int32, _P, _P]),
-    "gs_rasterize_fwd": (ctypes.c_int, [c_int32] * 5 + [_P, _P, _P, c_int64, _P, c_int32, _P, _P, _P, _P, _P, _P]),
+    "gs_isect_tile_sort_front": (ctypes.c_int, [c_int32, c_int32, c_int32, _P, c_int64, _P, _P, c_int32, _P, _P, _P, _P, _P]),
+    "gs_isect_tile_sort_redo": (ctypes.c_int, [c_int32, c_int32, c_int32, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gs_rasterize_fwd": (ctypes.c_int, [c_int32] * 5 + [_P, _P, _P, c_int64, _P, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, _P]),
     "gs_rasterize_bwd": (ctypes.c_int, [c_int32] * 5 + [_P, _P, _P, c_int64, _P, c_int32, _P, _P, _P, _P, _P, c_int32, _P, _P, _P]),
     "gs_raster_tile_order": (ctypes.c_int, [c_int32, _P, c_int64, _P, _P, _P, _P]),
     "gs_mark_visible": (ctypes.c_int, [c_int64, _P, _P, _P]),

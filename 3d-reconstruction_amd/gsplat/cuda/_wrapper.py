@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -241,12 +242,63 @@ def isect_tiles_from_splats(splats: Tensor, tiles_per_gauss: Tensor, tile_width:
     return isect_ids, flatten_ids
 
 
-def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
-                       tile_height: int) -> Tuple[Tensor, Tensor, Tensor, Optional[Tensor]]:
+_tls = threading.local()
+
+
+def take_front_sort():
+    """The FrontSort of this thread's last _RasterizeSplats.forward (None if its lists were sorted whole)."""
+    fs = getattr(_tls, "front_sort", None)
+    _tls.front_sort = None
+    return fs
+
+
+FRONT_SORT = True  # rasterization() sorts long tile lists front-first (False: every list whole, as gsplat does)
+FRONT_K_TARGET = 1024  # leading entries of a long tile list that the front sort orders (gs_isect_tile_sort_front)
+
+
+class FrontSort:
+    """State of a front-sorted intersection list (gs_isect_tile_sort_front): what is needed to sort the tiles the
+    rasterizer flags (`redo`) and to complete every tile when the caller reads the arrays (`finalize`)."""
+
+    def __init__(self, geom, offsets, order, n_long, pairs, isect_ids, flatten_ids, sorted_counts):
+        self.geom, self.offsets, self.order, self.n_long = geom, offsets, order, n_long
+        self.pairs, self.isect_ids, self.flatten_ids, self.sorted_counts = pairs, isect_ids, flatten_ids, sorted_counts
+        self.redo_flags = torch.zeros(sorted_counts.numel() + 1, device=sorted_counts.device, dtype=torch.int32)
+        self.complete = False
+
+    def redo(self) -> None:
+        C, tw, th = self.geom
+        dev = self.isect_ids.device
+        with torch.cuda.device(dev), B.timed("gs_isect_tile_sort_redo", dev):
+            B.check(B.lib().gs_isect_tile_sort_redo(C, tw, th, B.ptr(self.offsets), self.isect_ids.numel(),
+                                                    B.ptr(self.order), B.ptr(self.n_long), B.ptr(self.redo_flags),
+                                                    B.ptr(self.pairs), B.ptr(self.isect_ids), B.ptr(self.flatten_ids),
+                                                    B.ptr(self.sorted_counts), B.stream_handle(dev)),
+                    "gs_isect_tile_sort_redo")
+
+    def finalize(self) -> None:
+        """Sort every segment whole, in place (the already-sorted prefixes are rewritten with the same values)."""
+        if self.complete:
+            return
+        self.complete = True
+        C, tw, th = self.geom
+        dev = self.isect_ids.device
+        with torch.cuda.device(dev):
+            B.check(B.lib().gs_isect_tile_sort(C, tw, th, B.ptr(self.offsets), self.isect_ids.numel(),
+                                               B.ptr(self.order), B.ptr(self.n_long), B.ptr(self.pairs),
+                                               B.ptr(self.isect_ids), B.ptr(self.flatten_ids), B.stream_handle(dev)),
+                    "gs_isect_tile_sort")
+        self.pairs = None
+
+
+def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int, tile_height: int,
+                       front: bool = False):
     """isect_tiles + sort + isect_offset_encode in one binned pipeline (include/gsplat_mi355x.h, "binned isect_tiles").
-    Returns (isect_ids int64 [I] sorted, flatten_ids int32 [I], isect_offsets int32 [C,TH,TW], tile_order), the first
-    three bit-identical to `isect_tiles_from_splats(sort=True)` + `isect_offset_encode`; tile_order is the
-    longest-list-first tile permutation (int32 [C*TH*TW], or None) that the per-tile kernels are launched in."""
+    Returns (isect_ids int64 [I] sorted, flatten_ids int32 [I], isect_offsets int32 [C,TH,TW], tile_order, front_sort),
+    the first three bit-identical to `isect_tiles_from_splats(sort=True)` + `isect_offset_encode`; tile_order is the
+    longest-list-first tile permutation (int32 [C*TH*TW], or None) that the per-tile kernels are launched in.
+    front_sort is None unless front=True, when it is a `FrontSort`: only the leading entries of long tile lists are in
+    order until its `finalize()` runs."""
     dev = B.require_gpu(splats, tiles_per_gauss)
     C, N = tiles_per_gauss.shape
     T = tile_width * tile_height
@@ -273,15 +325,23 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
     isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64)
     flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
     if n_isects == 0:
-        return isect_ids, flatten_ids, offsets, None
+        return isect_ids, flatten_ids, offsets, None, None
     pairs = torch.empty(n_isects, device=dev, dtype=torch.int64)
     with torch.cuda.device(dev), B.timed("gs_isect_bin_scatter", dev):
         B.check(lib.gs_isect_bin_scatter(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss), n_slices,
                                          B.ptr(table), B.ptr(offsets), B.ptr(pairs), st), "gs_isect_bin_scatter")
+    if front and order is not None:
+        # `counts` (the list lengths) becomes sorted_counts: the front kernel overwrites the long tiles' entries
+        with torch.cuda.device(dev), B.timed("gs_isect_tile_sort", dev):
+            B.check(lib.gs_isect_tile_sort_front(C, tile_width, tile_height, B.ptr(offsets), n_isects, B.ptr(order),
+                                                 B.ptr(n_long), FRONT_K_TARGET, B.ptr(pairs), B.ptr(isect_ids),
+                                                 B.ptr(flatten_ids), B.ptr(counts), st), "gs_isect_tile_sort_front")
+        fs = FrontSort((C, tile_width, tile_height), offsets, order, n_long, pairs, isect_ids, flatten_ids, counts)
+        return isect_ids, flatten_ids, offsets, order, fs
     with torch.cuda.device(dev), B.timed("gs_isect_tile_sort", dev):
         B.check(lib.gs_isect_tile_sort(C, tile_width, tile_height, B.ptr(offsets), n_isects, B.ptr(order), B.ptr(n_long),
                                        B.ptr(pairs), B.ptr(isect_ids), B.ptr(flatten_ids), st), "gs_isect_tile_sort")
-    return isect_ids, flatten_ids, offsets, order
+    return isect_ids, flatten_ids, offsets, order, None
 
 
 def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
@@ -305,8 +365,10 @@ class _RasterizeSplats(torch.autograd.Function):
         dev = B.require_gpu(splats)
         C, N = tiles_per_gauss.shape
         TW, TH = math.ceil(width / tile_size), math.ceil(height / tile_size)
+        fs = None
         if TW * TH <= int(B.lib().gs_isect_bin_max_tiles()):
-            isect_ids, flatten_ids, offsets, order = isect_tiles_binned(splats, tiles_per_gauss, TW, TH)
+            isect_ids, flatten_ids, offsets, order, fs = isect_tiles_binned(splats, tiles_per_gauss, TW, TH,
+                                                                            front=FRONT_SORT)
         else:
             order = None
             isect_ids, flatten_ids = isect_tiles_from_splats(splats, tiles_per_gauss, TW, TH)
@@ -339,16 +401,30 @@ class _RasterizeSplats(torch.autograd.Function):
             with torch.cuda.device(dev), B.timed("gs_raster_tile_order", dev):
                 B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, None, B.ptr(order), None,
                                                      B.stream_handle(dev)), "gs_raster_tile_order")
-        with torch.cuda.device(dev), B.timed("gs_rasterize_fwd", dev):
-            B.check(B.lib().gs_rasterize_fwd(C, width, height, tile_size, channels, B.ptr(splats), B.ptr(offsets),
-                                             B.ptr(flatten_ids), n_isects, B.ptr(bg), int(ed), B.ptr(rc), B.ptr(ra),
-                                             B.ptr(last_ids), B.ptr(order), B.ptr(work), B.stream_handle(dev)),
-                    "gs_rasterize_fwd")
+        def raster(redo_pass: int) -> None:
+            with torch.cuda.device(dev), B.timed("gs_rasterize_fwd" if not redo_pass else "gs_rasterize_fwd_redo", dev):
+                B.check(B.lib().gs_rasterize_fwd(C, width, height, tile_size, channels, B.ptr(splats), B.ptr(offsets),
+                                                 B.ptr(flatten_ids), n_isects, B.ptr(bg), int(ed), B.ptr(rc), B.ptr(ra),
+                                                 B.ptr(last_ids), B.ptr(order), B.ptr(work),
+                                                 B.ptr(fs.sorted_counts) if fs is not None else None,
+                                                 B.ptr(fs.redo_flags) if fs is not None else None, redo_pass,
+                                                 B.stream_handle(dev)), "gs_rasterize_fwd")
+
+        raster(0)
+        if fs is not None:
+            # tiles whose pixels were still live at the end of their sorted front: sort those lists whole and rasterize
+            # them again (both launches visit flagged tiles only; usually there are none)
+            fs.redo()
+            raster(1)
+        _tls.front_sort = fs  # handed to rasterization() for the lazy completion of meta["isect_ids"/"flatten_ids"]
+        order_bwd = None
         if work is not None:
+            # (a tensor of its own: `order` and its size classes still describe the sort launches of `fs`)
+            order_bwd = torch.empty_like(order)
             with torch.cuda.device(dev), B.timed("gs_raster_tile_order", dev):
-                B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, B.ptr(work), B.ptr(order), None,
-                                                     B.stream_handle(dev)), "gs_raster_tile_order")
-        ctx.tile_order = order if work is not None else None
+                B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, B.ptr(work), B.ptr(order_bwd),
+                                                     None, B.stream_handle(dev)), "gs_raster_tile_order")
+        ctx.tile_order = order_bwd
         ctx.geom = (C, N, width, height, tile_size, channels, int(ed), bool(absgrad))
         ctx.has_bg = bg is not None
         ctx.has_packed = packed_index is not None

@@ -23,6 +23,50 @@ from . import _backend as B
 from .cuda import _wrapper as W
 
 
+class _Meta(dict):
+    """`meta` of rasterization().  Long tile lists are sorted front-first (only what the compositor reads); the
+    `isect_ids` / `flatten_ids` arrays are completed in place, to gsplat's full sorted order, the first time either
+    is read through this dict."""
+
+    _LAZY = ("isect_ids", "flatten_ids")
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self._front_sort = None
+
+    def _complete(self):
+        fs, self._front_sort = self._front_sort, None
+        if fs is not None:
+            fs.finalize()
+
+    def __getitem__(self, key):
+        if key in self._LAZY:
+            self._complete()
+        return super().__getitem__(key)
+
+    def get(self, key, default=None):
+        if key in self._LAZY:
+            self._complete()
+        return super().get(key, default)
+
+    def pop(self, key, *default):
+        if key in self._LAZY:
+            self._complete()
+        return super().pop(key, *default)
+
+    def items(self):
+        self._complete()
+        return super().items()
+
+    def values(self):
+        self._complete()
+        return super().values()
+
+    def copy(self):
+        self._complete()
+        return dict(self)
+
+
 def _as_int(v) -> int:
     # the reference passes 0-d / 1-element CUDA long tensors for width/height
     # (/root/reference/3D-Reconstruction-main/datasets/base/pixel_source.py:653-654, :1111-1112)
@@ -131,7 +175,7 @@ def rasterization(
         means, quats, scales, opacities, col_in, viewmats, Ks, campos, params)
 
     TW, TH = math.ceil(width / tile_size), math.ceil(height / tile_size)
-    meta: Dict = {}
+    meta: Dict = _Meta()
     packed_index = None
     hook = means2d
     if packed:
@@ -144,6 +188,7 @@ def rasterization(
                      "opacities": splats.detach().reshape(-1, B.GS_REC)[packed_index, 5]})
     render_colors, render_alphas, isect_ids, flatten_ids, isect_offsets, last_ids = W._RasterizeSplats.apply(
         splats, hook, tiles_per_gauss, bg, width, height, tile_size, channels, ed, absgrad, packed_index)
+    meta._front_sort = W.take_front_sort()
 
     if not packed:
         sd = splats.detach()

@@ -188,6 +188,22 @@ int gs_isect_tile_sort(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t*
                        uint64_t* pairs, int64_t* isect_ids /* out [n_isects] */, int32_t* flatten_ids /* out */,
                        void* stream);
 
+/* Front-only variant of gs_isect_tile_sort (no reference counterpart: gsplat sorts every key).  Segments longer than
+ * 1024 entries get only their leading >= k_target entries (1 <= k_target <= 1024) sorted and written to
+ * isect_ids / flatten_ids; sorted_counts[tile] (pre-filled by the caller with the list lengths) receives that count.
+ * Shorter segments, and long ones whose front is degenerate, are sorted whole.  The written prefix of every segment is
+ * bit-identical to the same positions of gs_isect_tile_sort's output; the rest of isect_ids / flatten_ids is
+ * unspecified until gs_isect_tile_sort_redo (tiles with redo_flags != 0, as set by gs_rasterize_fwd) or
+ * gs_isect_tile_sort (every tile; `pairs` stays valid for both) completes it.  tile_order and size_classes are required. */
+int gs_isect_tile_sort_front(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets, int64_t n_isects,
+                             const int32_t* tile_order, const int32_t* size_classes, int32_t k_target, uint64_t* pairs,
+                             int64_t* isect_ids, int32_t* flatten_ids, int32_t* sorted_counts /* in/out */, void* stream);
+int gs_isect_tile_sort_redo(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets, int64_t n_isects,
+                            const int32_t* tile_order, const int32_t* size_classes,
+                            const int32_t* redo_flags /* [C*tile_h*tile_w + 1], last element = number of flagged tiles */,
+                            uint64_t* pairs, int64_t* isect_ids, int32_t* flatten_ids, int32_t* sorted_counts,
+                            void* stream);
+
 /* ---- rasterize_to_pixels ---------------------------------------------------------------------- */
 int gs_rasterize_fwd(int32_t C, int32_t width, int32_t height, int32_t tile_size,
                      int32_t channels,            /* 1..4 colour channels of the splat record */
@@ -202,6 +218,13 @@ int gs_rasterize_fwd(int32_t C, int32_t width, int32_t height, int32_t tile_size
                      int32_t* last_ids,           /* out [C,H,W]          */
                      const int32_t* tile_order,   /* [C*tile_h*tile_w] launch order of the tiles (gs_raster_tile_order) or NULL */
                      int32_t* tile_work,          /* out [C*tile_h*tile_w] list entries the backward will walk, or NULL */
+                     const int32_t* sorted_counts,/* [C*tile_h*tile_w] from gs_isect_tile_sort_front: only that many leading
+                                                     entries of a tile's list are sorted yet; NULL = lists fully sorted */
+                     int32_t* redo_flags,         /* in/out [C*tile_h*tile_w + 1], zeroed by the caller; needed with
+                                                     sorted_counts.  Pass 0 sets 1 where pixels were still live at the end
+                                                     of the sorted front and counts those tiles in the last element;
+                                                     pass 1 rasterizes exactly those tiles again */
+                     int32_t redo_pass,           /* 0: normal launch; 1: after gs_isect_tile_sort_redo */
                      void* stream);
 
 int gs_rasterize_bwd(int32_t C, int32_t width, int32_t height, int32_t tile_size,

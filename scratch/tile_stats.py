@@ -6,7 +6,7 @@ for p in (ROOT, os.path.join(ROOT, "3d-reconstruction_amd")):
 import torch, synth_scene
 from gsplat.rendering import rasterization
 dev = torch.device("cuda:0")
-N, C, W, H = 1_000_000, 5, 1242, 375
+N, C, W, H = (int(a) for a in sys.argv[1:5]) if len(sys.argv) > 4 else (1_000_000, 5, 1242, 375)
 g = synth_scene.make_gaussians(N, sh_degree=3)
 p = {k: v.to(dev) for k, v in g.items()}
 vm, Ks = synth_scene.make_cameras(C, W, H)
@@ -32,3 +32,4 @@ for name, v in (("list length", L), ("walked", walked)):
 srt = torch.sort(walked, descending=True).values
 print("top walked:", srt[:20].tolist())
 print("tiles with walked > 1000:", int((walked > 1000).sum()), " > 2000:", int((walked > 2000).sum()))
+print("tiles with list > 2048:", int((L > 2048).sum()), "> 6144:", int((L > 6144).sum()), "of", L.numel(), " walked/listed =", float(walked.sum()) / float(L.sum()))

@@ -1,0 +1,117 @@
+"""Front-first tile sort (gs_isect_tile_sort_front / _redo, no gsplat counterpart): long tile lists get only their leading
+entries sorted before the rasterizer runs.  Observable results must not change: the sorted prefix equals the same
+positions of the full A.3 order bit for bit, meta["isect_ids"/"flatten_ids"] read through `meta` are the full sorted
+arrays, images are bit-identical to the whole-list sort, and a tile whose pixels outlive the front is redone."""
+import numpy as np
+import pytest
+import torch
+
+import synth_scene
+from test_gpu_parity import _synthetic_records
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("C,N,TW,TH,hot,levels", [
+    (2, 20_000, 13, 7, 6000, 1 << 20),  # long segments, spread depths: fronts of ~768
+    (2, 20_000, 13, 7, 6000, 5),        # 5 distinct depths: every front has a crowded bucket -> deferred, sorted whole
+    (1, 3_000, 5, 4, 1500, 1 << 20),
+    (3, 500, 78, 24, 0, 3),             # nothing longer than 1024: the short classes only
+])
+def test_front_prefix_matches_full_order(gpu_device, C, N, TW, TH, hot, levels):
+    from gsplat.cuda._wrapper import FRONT_K_TARGET, isect_tiles_binned
+
+    rng = np.random.default_rng(7 + C * 1000 + N)
+    rec, tiles, keys, ids, offsets = _synthetic_records(rng, C, N, TW, TH, hot, levels, gpu_device)
+    k, f, o, order, fs = isect_tiles_binned(rec, tiles, TW, TH, front=True)
+    assert np.array_equal(o.cpu().numpy(), offsets)
+    assert fs is not None
+    off = offsets.reshape(-1).astype(np.int64)
+    end = np.append(off[1:], len(keys))
+    n = end - off
+    sc = fs.sorted_counts.cpu().numpy().astype(np.int64)
+    assert np.all(sc >= 0) and np.all(sc <= n)
+    assert np.all(sc[n <= 1024] == n[n <= 1024])          # short lists are sorted whole
+    assert np.all(sc[n > 1024] >= min(FRONT_K_TARGET, 1024))  # a front holds at least k_target entries
+    kg, fg = k.cpu().numpy(), f.cpu().numpy()
+    for t in range(len(off)):
+        a, m = off[t], sc[t]
+        assert np.array_equal(kg[a:a + m], keys[a:a + m]), t
+        assert np.array_equal(fg[a:a + m], ids[a:a + m]), t
+    # flag every other long tile, redo: those become whole; then finalize: everything is
+    long_tiles = np.nonzero(sc < n)[0]
+    flags = np.zeros(len(off), np.int32)
+    flags[long_tiles[::2]] = 1
+    fs.redo_flags.copy_(torch.from_numpy(np.append(flags, flags.sum()).astype(np.int32)).to(gpu_device))
+    fs.redo()
+    sc2 = fs.sorted_counts.cpu().numpy().astype(np.int64)
+    assert np.all(sc2[flags == 1] == n[flags == 1]) and np.all(sc2[flags == 0] == sc[flags == 0])
+    kg, fg = k.cpu().numpy(), f.cpu().numpy()
+    for t in long_tiles[::2]:
+        assert np.array_equal(kg[off[t]:end[t]], keys[off[t]:end[t]]) and np.array_equal(fg[off[t]:end[t]], ids[off[t]:end[t]])
+    fs.finalize()
+    assert np.array_equal(k.cpu().numpy(), keys) and np.array_equal(f.cpu().numpy(), ids)
+
+
+def _dense_scene(n, opac_lo, opac_hi, seed=3):
+    g = synth_scene.make_gaussians(n, sh_degree=None, seed=seed, extent=6.0)
+    gen = torch.Generator().manual_seed(seed + 1)
+    g["means"][:, 2] = torch.rand(n, generator=gen) * 3.0 + 0.2
+    g["scales"] = g["scales"] * 1.5
+    g["opacities"] = opac_lo + (opac_hi - opac_lo) * torch.rand(n, generator=gen)
+    return g
+
+
+@pytest.mark.parametrize("opac,expect_redo", [((0.3, 0.95), False), ((0.002, 0.01), True)])
+def test_front_sort_renders_identically(gpu_device, opac, expect_redo):
+    """End to end: front-first sort (+ redo pass for tiles whose pixels outlive the front) against sorting every list
+    whole.  Forward outputs and the lazily completed isect arrays bit for bit; gradients to fp32 atomic-order noise."""
+    import gsplat.cuda._wrapper as W
+    from gsplat.rendering import rasterization
+
+    dev = gpu_device
+    N, Wd, Hd = 120_000, 160, 96
+    g = _dense_scene(N, *opac)
+    vm, Ks = synth_scene.make_cameras(2, Wd, Hd)
+    gen = torch.Generator().manual_seed(11)
+    wc = torch.randn(2, Hd, Wd, 4, generator=gen).to(dev)
+    wa = torch.randn(2, Hd, Wd, 1, generator=gen).to(dev)
+
+    def run(front):
+        old = W.FRONT_SORT
+        W.FRONT_SORT = front
+        try:
+            p = {k: v.to(dev).requires_grad_(True) for k, v in g.items()}
+            rc, ra, meta = rasterization(p["means"], p["quats"], p["scales"], p["opacities"], p["colors"], vm.to(dev),
+                                         Ks.to(dev), Wd, Hd, near_plane=0.1, packed=False, render_mode="RGB+ED",
+                                         absgrad=True, rasterize_mode="antialiased")
+            fs = meta._front_sort
+            stats = None
+            if fs is not None:
+                off = meta["isect_offsets"].reshape(-1).long()
+                n = torch.diff(torch.cat([off, torch.tensor([fs.isect_ids.numel()], device=dev)]))
+                stats = (int((fs.sorted_counts < n).sum()), int(fs.redo_flags[:-1].sum()), int((n > 1024).sum()))
+            ((rc * wc).sum() + (ra * wa).sum()).backward()
+            grads = {k: v.grad.clone() for k, v in p.items()}
+            grads["absgrad"] = meta["means2d"].absgrad.clone()
+            return rc, ra, meta, grads, stats
+        finally:
+            W.FRONT_SORT = old
+
+    rc1, ra1, m1, g1, st = run(True)
+    rc0, ra0, m0, g0, st0 = run(False)
+    assert st0 is None and st is not None
+    n_front, n_redo, n_long = st
+    print(f"[front] long tiles {n_long}, front-sorted {n_front}, redone {n_redo}")
+    # (a redone tile counts as whole again, so "front-sorted" is what is still partial after the redo pass)
+    assert n_long > 0 and n_front + n_redo > 0, "the scene does not exercise the front sort"
+    assert (n_redo > 0) == expect_redo, (n_redo, expect_redo)
+    assert torch.equal(rc1, rc0) and torch.equal(ra1, ra0)
+    assert torch.equal(m1["last_ids"], m0["last_ids"])
+    assert torch.equal(m1["isect_offsets"], m0["isect_offsets"])
+    assert torch.equal(m1["flatten_ids"], m0["flatten_ids"])  # completes the tails on access
+    assert torch.equal(m1["isect_ids"], m0["isect_ids"])
+    for k in g0:
+        a, b = g1[k].double(), g0[k].double()
+        rel = float((a - b).norm() / (b.norm() + 1e-30))
+        assert rel < 1e-5, (k, rel)

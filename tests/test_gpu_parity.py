@@ -145,7 +145,7 @@ def test_binned_isect_matches_stable_sort(gpu_device, C, N, TW, TH, hot, levels)
     rng = np.random.default_rng(C * 1000 + N)
     rec, tiles, keys, ids, offsets = _synthetic_records(rng, C, N, TW, TH, hot, levels, gpu_device)
     for _ in range(2):  # the scatter order inside a segment is arbitrary; the result must not be
-        k, f, o, order = isect_tiles_binned(rec, tiles, TW, TH)
+        k, f, o, order, _ = isect_tiles_binned(rec, tiles, TW, TH)
         assert np.array_equal(k.cpu().numpy(), keys)
         assert np.array_equal(f.cpu().numpy(), ids)
         assert np.array_equal(o.cpu().numpy(), offsets)
@@ -163,7 +163,7 @@ def test_binned_isect_empty(gpu_device):
 
     rec = torch.zeros(2, 100, B.GS_REC, device=gpu_device)
     tiles = torch.zeros(2, 100, dtype=torch.int32, device=gpu_device)
-    k, f, o, _ = isect_tiles_binned(rec, tiles, 4, 3)
+    k, f, o, _, _ = isect_tiles_binned(rec, tiles, 4, 3)
     assert k.numel() == 0 and f.numel() == 0 and int(o.abs().sum()) == 0 and o.shape == (2, 3, 4)
 
 
