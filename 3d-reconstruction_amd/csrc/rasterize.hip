@@ -146,7 +146,8 @@ __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
     const int32_t* __restrict__ flatten_ids, int64_t n_isects, const float* __restrict__ backgrounds, int ed,
     float* __restrict__ out_c, float* __restrict__ out_a, int32_t* __restrict__ last_ids,
     const int32_t* __restrict__ tile_order, int32_t* __restrict__ tile_work,
-    const int32_t* __restrict__ sorted_cnt, int32_t* __restrict__ redo_flags, int redo_pass) {
+    const int32_t* __restrict__ sorted_cnt, int32_t* __restrict__ redo_flags, int redo_pass,
+    const float* __restrict__ opac_override, int n_per_cam) {
   __shared__ float4 sg[Q_SLOTS * 3];
   __shared__ unsigned short qidx[4 * Q_STRIDE];
   const unsigned n_tiles = (unsigned)(C * TW * TH);
@@ -193,8 +194,11 @@ __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
   auto prefetch = [&](int b) {
     const int k = tg.start + b * 64 + lane;
     if (k < tg.end) {
-      const float4* r = reinterpret_cast<const float4*>(splats + (int64_t)flatten_ids[k] * REC);
+      const int row = flatten_ids[k];
+      const float4* r = reinterpret_cast<const float4*>(splats + (int64_t)row * REC);
       n0 = r[0]; n1 = r[1]; n2 = r[2];
+      // re-render of cached records with other opacities (per-class masks of the eval path): opacity x compensation
+      if (opac_override) n1.y = opac_override[row % n_per_cam] * splats[(int64_t)row * REC + 12];
     }
   };
   if (nbatch > 0) prefetch(0);
@@ -601,7 +605,7 @@ static int raster_check(int32_t C, int32_t width, int32_t height, int32_t tile_s
   return GS_OK;
 }
 
-#define GS_RF_ARGS C, width, height, TW, TH, splats, isect_offsets, flatten_ids, n_isects, backgrounds, ed_last_channel, render_colors, render_alphas, last_ids, tile_order, tile_work, sorted_counts, redo_flags, redo_pass
+#define GS_RF_ARGS C, width, height, TW, TH, splats, isect_offsets, flatten_ids, n_isects, backgrounds, ed_last_channel, render_colors, render_alphas, last_ids, tile_order, tile_work, sorted_counts, redo_flags, redo_pass, opacity_override, n_per_camera
 #define GS_RF_LAUNCH(CHN) hipLaunchKernelGGL((gs::rasterize_fwd_kernel<CHN>), grid, block, 0, s, GS_RF_ARGS)
 
 extern "C" int gs_rasterize_fwd(int32_t C, int32_t width, int32_t height, int32_t tile_size, int32_t channels,
@@ -609,11 +613,13 @@ extern "C" int gs_rasterize_fwd(int32_t C, int32_t width, int32_t height, int32_
                                 int64_t n_isects, const float* backgrounds, int32_t ed_last_channel,
                                 float* render_colors, float* render_alphas, int32_t* last_ids,
                                 const int32_t* tile_order, int32_t* tile_work, const int32_t* sorted_counts,
-                                int32_t* redo_flags, int32_t redo_pass, void* stream) {
+                                int32_t* redo_flags, int32_t redo_pass, const float* opacity_override,
+                                int32_t n_per_camera, void* stream) {
   int st = raster_check(C, width, height, tile_size, channels, n_isects);
   if (st != GS_OK) return st;
   if (!isect_offsets || !render_colors || !render_alphas || !last_ids) return GS_ERR_INVALID_ARG;
   if ((sorted_counts || redo_pass) && !redo_flags) return GS_ERR_INVALID_ARG;
+  if (opacity_override && n_per_camera < 1) return GS_ERR_INVALID_ARG;
   if (n_isects > 0 && (!splats || !flatten_ids)) return GS_ERR_INVALID_ARG;
   const int TW = (width + 15) / 16, TH = (height + 15) / 16;
   hipStream_t s = (hipStream_t)stream;

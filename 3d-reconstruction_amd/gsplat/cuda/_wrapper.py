@@ -288,7 +288,7 @@ class FrontSort:
                                                B.ptr(self.order), B.ptr(self.n_long), B.ptr(self.pairs),
                                                B.ptr(self.isect_ids), B.ptr(self.flatten_ids), B.stream_handle(dev)),
                     "gs_isect_tile_sort")
-        self.pairs = None
+        self.pairs = None  # (stream-ordered: the allocator reuses it only behind the sort)
 
 
 def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int, tile_height: int,
@@ -355,6 +355,55 @@ def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile
 
 
 # ----------------------------------------------------------------------------- rasterize
+def launch_raster_fwd(splats, offsets, flatten_ids, order, fs, bg, geom, rc, ra, last_ids, work, opac_override) -> None:
+    """gs_rasterize_fwd (+ the redo pass of front-sorted lists) into preallocated outputs."""
+    C, N, width, height, tile_size, channels, ed = geom
+    dev = splats.device
+    n_isects = flatten_ids.numel()
+    if fs is not None and fs.complete:  # every list has been sorted whole since (meta["flatten_ids"] was read)
+        fs = None
+
+    def raster(redo_pass: int) -> None:
+        with torch.cuda.device(dev), B.timed("gs_rasterize_fwd" if not redo_pass else "gs_rasterize_fwd_redo", dev):
+            B.check(B.lib().gs_rasterize_fwd(C, width, height, tile_size, channels, B.ptr(splats), B.ptr(offsets),
+                                             B.ptr(flatten_ids), n_isects, B.ptr(bg), int(ed), B.ptr(rc), B.ptr(ra),
+                                             B.ptr(last_ids), B.ptr(order), B.ptr(work),
+                                             B.ptr(fs.sorted_counts) if fs is not None else None,
+                                             B.ptr(fs.redo_flags) if fs is not None else None, redo_pass,
+                                             B.ptr(opac_override), N, B.stream_handle(dev)), "gs_rasterize_fwd")
+
+    raster(0)
+    if fs is not None:
+        # tiles whose pixels were still live at the end of their sorted front: sort those lists whole and rasterize
+        # them again (both launches visit flagged tiles only; usually there are none)
+        fs.redo()
+        raster(1)
+
+
+def take_raster_state():
+    """(splats, offsets, isect_ids, flatten_ids, tile_order, front_sort) of this thread's last _RasterizeSplats.forward:
+    what a re-render with other opacities needs (gsplat.rendering's eval cache)."""
+    st = getattr(_tls, "raster_state", None)
+    _tls.raster_state = None
+    return st
+
+
+def rerender(state, opacities: Tensor, backgrounds, geom):
+    """Rasterize cached records again with `opacities` [N] in place of the ones they were projected with (no grad)."""
+    splats, offsets, isect_ids, flatten_ids, order, fs = state
+    C, N, width, height, tile_size, channels, ed = geom
+    dev = splats.device
+    rc = torch.empty(C, height, width, channels, device=dev, dtype=torch.float32)
+    ra = torch.empty(C, height, width, 1, device=dev, dtype=torch.float32)
+    last_ids = torch.empty(C, height, width, device=dev, dtype=torch.int32)
+    if fs is not None:
+        fs.redo_flags.zero_()
+    bg = B.f32c(backgrounds) if backgrounds is not None else None
+    launch_raster_fwd(splats, offsets, flatten_ids, order if flatten_ids.numel() > 0 else None, fs, bg, geom, rc, ra,
+                      last_ids, None, B.f32c(opacities))
+    return rc, ra, last_ids
+
+
 class _RasterizeSplats(torch.autograd.Function):
     """splat records -> (render_colors [C,H,W,CH], render_alphas [C,H,W,1]); tile intersection, sort and
     offsets (integer, non-differentiable) run inside forward."""
@@ -401,22 +450,10 @@ class _RasterizeSplats(torch.autograd.Function):
             with torch.cuda.device(dev), B.timed("gs_raster_tile_order", dev):
                 B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, None, B.ptr(order), None,
                                                      B.stream_handle(dev)), "gs_raster_tile_order")
-        def raster(redo_pass: int) -> None:
-            with torch.cuda.device(dev), B.timed("gs_rasterize_fwd" if not redo_pass else "gs_rasterize_fwd_redo", dev):
-                B.check(B.lib().gs_rasterize_fwd(C, width, height, tile_size, channels, B.ptr(splats), B.ptr(offsets),
-                                                 B.ptr(flatten_ids), n_isects, B.ptr(bg), int(ed), B.ptr(rc), B.ptr(ra),
-                                                 B.ptr(last_ids), B.ptr(order), B.ptr(work),
-                                                 B.ptr(fs.sorted_counts) if fs is not None else None,
-                                                 B.ptr(fs.redo_flags) if fs is not None else None, redo_pass,
-                                                 B.stream_handle(dev)), "gs_rasterize_fwd")
-
-        raster(0)
-        if fs is not None:
-            # tiles whose pixels were still live at the end of their sorted front: sort those lists whole and rasterize
-            # them again (both launches visit flagged tiles only; usually there are none)
-            fs.redo()
-            raster(1)
-        _tls.front_sort = fs  # handed to rasterization() for the lazy completion of meta["isect_ids"/"flatten_ids"]
+        launch_raster_fwd(splats, offsets, flatten_ids, order, fs, bg, (C, N, width, height, tile_size, channels, ed),
+                          rc, ra, last_ids, work, None)
+        _tls.front_sort = fs
+        _tls.raster_state = (splats, offsets, isect_ids, flatten_ids, order, fs)  # handed to rasterization() for the lazy completion of meta["isect_ids"/"flatten_ids"]
         order_bwd = None
         if work is not None:
             # (a tensor of its own: `order` and its size classes still describe the sort launches of `fs`)

@@ -14,6 +14,7 @@ Pipeline (two autograd nodes, five kernels + an integer sort):
 from __future__ import annotations
 
 import math
+import threading
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -33,25 +34,28 @@ class _Meta(dict):
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
         self._front_sort = None
+        self._thunks = {}  # key -> callable producing the value on first read (the key is present, holding None)
 
-    def _complete(self):
-        fs, self._front_sort = self._front_sort, None
-        if fs is not None:
-            fs.finalize()
+    def _complete(self, key=None):
+        if key is None or key in self._LAZY:
+            fs, self._front_sort = self._front_sort, None
+            if fs is not None:
+                fs.finalize()
+        for k in ([key] if key is not None else list(self._thunks)):
+            th = self._thunks.pop(k, None)
+            if th is not None:
+                super().__setitem__(k, th())
 
     def __getitem__(self, key):
-        if key in self._LAZY:
-            self._complete()
+        self._complete(key)
         return super().__getitem__(key)
 
     def get(self, key, default=None):
-        if key in self._LAZY:
-            self._complete()
+        self._complete(key)
         return super().get(key, default)
 
     def pop(self, key, *default):
-        if key in self._LAZY:
-            self._complete()
+        self._complete(key)
         return super().pop(key, *default)
 
     def items(self):
@@ -65,6 +69,29 @@ class _Meta(dict):
     def copy(self):
         self._complete()
         return dict(self)
+
+
+# ---- eval re-render cache ------------------------------------------------------------------------------------------
+# The reference's eval path renders one image up to six times with the same Gaussians and camera and only the
+# opacities masked per class (/root/reference/3D-Reconstruction-main/models/trainers/scene_graph.py:282-301 through
+# models/trainers/base.py:392-408).  Projection, tile intersection and sort do not depend on the opacities, so under
+# no_grad the last call's splat records and sorted lists are kept and a call that differs only in `opacities` (and
+# `backgrounds`) goes straight to the rasterizer, which takes the new opacities as an override.  Results are bit-identical
+# to an independent call (same kernels, same lists).  Keyed on the identity + in-place version of the Gaussian tensors
+# and on the values of viewmats / Ks (the reference inverts camtoworlds afresh on every call).
+EVAL_CACHE = True
+_cache = threading.local()
+
+
+def clear_cache() -> None:
+    """Drop the cached records of the last no-grad call (they pin C*N*64 bytes of device memory)."""
+    _cache.entry = None
+
+
+def _cache_key(means, quats, scales, colors, viewmats, Ks, scalars):
+    tens = tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype, str(t.device)) for t in (means, quats, scales, colors))
+    cams = torch.cat([viewmats.detach().reshape(-1).float(), Ks.detach().reshape(-1).float()]).cpu().numpy().tobytes()
+    return tens + (cams,) + scalars
 
 
 def _as_int(v) -> int:
@@ -169,6 +196,29 @@ def rasterization(
     else:
         bg = None
 
+    # ---- eval re-render cache (see EVAL_CACHE above)
+    geom = (C, N, width, height, tile_size, channels, ed)
+    needs_grad = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in (means, quats, scales, opacities, colors, viewmats, backgrounds))
+    use_cache = EVAL_CACHE and not packed and N > 0 and not needs_grad
+    key = None
+    if needs_grad:
+        _cache.entry = None  # a training step: do not keep the last eval image's records alive
+    elif use_cache:
+        key = _cache_key(means, quats, scales, colors, viewmats, Ks,
+                         (geom, float(near_plane), float(far_plane), float(radius_clip), float(eps2d), sh_degree,
+                          render_mode, rasterize_mode))
+        ent = getattr(_cache, "entry", None)
+        if ent is not None and ent["key"] == key:
+            rc, ra, last_ids = W.rerender(ent["state"], opacities, bg, geom)
+            meta = _Meta(ent["meta"])
+            meta["last_ids"] = last_ids
+            meta["opacities"] = None
+            sd, op = ent["state"][0], opacities
+            meta._thunks["opacities"] = lambda: op[None, :] * sd[..., 12]
+            meta._front_sort = ent["state"][5]
+            return rc, ra, meta
+
     params = W._make_params(N, C, width, height, tile_size, eps2d, near_plane, far_plane, radius_clip,
                             rasterize_mode == "antialiased", color_mode, color_dim, sh_degree, sh_K, want_depth)
     splats, means2d, radii, tiles_per_gauss = W._ProjectSplats.apply(
@@ -189,6 +239,7 @@ def rasterization(
     render_colors, render_alphas, isect_ids, flatten_ids, isect_offsets, last_ids = W._RasterizeSplats.apply(
         splats, hook, tiles_per_gauss, bg, width, height, tile_size, channels, ed, absgrad, packed_index)
     meta._front_sort = W.take_front_sort()
+    state = W.take_raster_state()
 
     if not packed:
         sd = splats.detach()
@@ -199,6 +250,10 @@ def rasterization(
         "flatten_ids": flatten_ids, "isect_offsets": isect_offsets, "last_ids": last_ids,
         "width": width, "height": height, "tile_size": tile_size, "n_cameras": C,
     })
+    if use_cache and state is not None:
+        # a plain-dict snapshot of the call-independent entries (reading dict.items of the base class: no completion)
+        _cache.entry = {"key": key, "state": state, "pins": (means, quats, scales, colors),
+                        "meta": {k: v for k, v in dict.items(meta) if k not in ("last_ids", "opacities")}}
     return render_colors, render_alphas, meta
 
 

@@ -225,6 +225,11 @@ int gs_rasterize_fwd(int32_t C, int32_t width, int32_t height, int32_t tile_size
                                                      of the sorted front and counts those tiles in the last element;
                                                      pass 1 rasterizes exactly those tiles again */
                      int32_t redo_pass,           /* 0: normal launch; 1: after gs_isect_tile_sort_redo */
+                     const float* opacity_override,/* [n_per_camera] or NULL: composite with opacity_override[row %
+                                                     n_per_camera] * compensation instead of the record's opacity (the
+                                                     reference's per-class re-renders, R/models/trainers/scene_graph.py:
+                                                     282-301, reuse one projection + sort and change only this) */
+                     int32_t n_per_camera,        /* N: rows per camera of `splats` (used with opacity_override) */
                      void* stream);
 
 int gs_rasterize_bwd(int32_t C, int32_t width, int32_t height, int32_t tile_size,
