@@ -1,0 +1,65 @@
+"""Render-only trajectory harness (BASELINE configs[4]).
+
+The reference renders a novel-view trajectory one frame at a time and blocks on `outputs["rgb"].cpu().numpy()` twice
+per frame before the next frame is even projected
+(/root/reference/3D-Reconstruction-main/models/video_utils.py:647-706).  Here the views of a trajectory are sharded
+contiguously over the ranks (no collective: every rank holds all Gaussians and writes its own frames), rendered
+`views_per_call` at a time under no_grad, converted on the device exactly as the reference converts on the host
+(`clip(1e-6, 1 - 1e-6) * 255 -> uint8`, or left as float32), and copied into one pinned host buffer on a side stream
+while the next batch renders.  One host synchronisation at the end.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _backend as B
+from .distributed import shard_views
+from .rendering import no_eval_cache, rasterization
+
+
+def frames_to_uint8(rgb: Tensor) -> Tensor:
+    """video_utils.py:694-700: `rgb.clip(min=1e-6, max=1 - 1e-6)`, `(rgb * 255).astype(np.uint8)` (truncation)."""
+    return (rgb.clamp(1.0e-6, 1.0 - 1.0e-6) * 255.0).to(torch.uint8)
+
+
+def render_trajectory(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Tensor,
+                      viewmats: Tensor, Ks: Tensor, width: int, height: int, *, sh_degree: Optional[int] = None,
+                      views_per_call: int = 4, rank: int = 0, world_size: int = 1, as_uint8: bool = True,
+                      out: Optional[Tensor] = None, **raster_kwargs) -> Tuple[Tensor, range]:
+    """Render views `shard_views(V, rank, world_size)` of a [V,4,4] / [V,3,3] trajectory.
+
+    Returns (frames, view_range): frames is a pinned host tensor [len(view_range), H, W, 3] (uint8, or float32 with
+    as_uint8=False) holding the RGB channels; `out` may supply it.  Extra keyword arguments go to `rasterization`
+    (near_plane, far_plane, packed, rasterize_mode, backgrounds per view [V,3], ...).  Device tensors only."""
+    dev = B.require_gpu(means, quats, scales, opacities, colors, viewmats, Ks)
+    V = viewmats.shape[0]
+    assert viewmats.shape == (V, 4, 4) and Ks.shape == (V, 3, 3), (viewmats.shape, Ks.shape)
+    assert views_per_call >= 1
+    mine = shard_views(V, rank, world_size)
+    n_mine = len(mine)
+    dtype = torch.uint8 if as_uint8 else torch.float32
+    if out is None:
+        out = torch.empty(n_mine, height, width, 3, dtype=dtype, pin_memory=True)
+    assert out.shape == (n_mine, height, width, 3) and out.dtype == dtype and out.device.type == "cpu"
+    backgrounds = raster_kwargs.pop("backgrounds", None)
+    raster_kwargs.setdefault("packed", True)
+    raster_kwargs.setdefault("render_mode", "RGB")
+    main = torch.cuda.current_stream(dev)
+    copy = B.side_stream(dev)
+    with torch.no_grad(), no_eval_cache():  # every batch is a new camera set: nothing to reuse
+        for b0 in range(0, n_mine, views_per_call):
+            idx = slice(mine.start + b0, mine.start + min(b0 + views_per_call, n_mine))
+            bg = backgrounds[idx] if backgrounds is not None else None
+            rc, _, _ = rasterization(means, quats, scales, opacities, colors, viewmats[idx], Ks[idx], width, height,
+                                     sh_degree=sh_degree, backgrounds=bg, **raster_kwargs)
+            frames = rc[..., :3]
+            frames = frames_to_uint8(frames) if as_uint8 else frames.contiguous()
+            copy.wait_stream(main)
+            with torch.cuda.stream(copy):
+                out[b0:b0 + frames.shape[0]].copy_(frames, non_blocking=True)
+            frames.record_stream(copy)
+    copy.synchronize()
+    return out, mine

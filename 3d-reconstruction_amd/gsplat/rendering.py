@@ -83,6 +83,18 @@ EVAL_CACHE = True
 _cache = threading.local()
 
 
+class no_eval_cache:
+    """Context manager: calls on this thread neither consult nor fill the eval cache (and skip its key's host sync)."""
+
+    def __enter__(self):
+        self.prev = getattr(_cache, "disabled", False)
+        _cache.disabled = True
+
+    def __exit__(self, *exc):
+        _cache.disabled = self.prev
+        return False
+
+
 def clear_cache() -> None:
     """Drop the cached records of the last no-grad call (they pin C*N*64 bytes of device memory)."""
     _cache.entry = None
@@ -200,7 +212,7 @@ def rasterization(
     geom = (C, N, width, height, tile_size, channels, ed)
     needs_grad = torch.is_grad_enabled() and any(
         t is not None and t.requires_grad for t in (means, quats, scales, opacities, colors, viewmats, backgrounds))
-    use_cache = EVAL_CACHE and not packed and N > 0 and not needs_grad
+    use_cache = (EVAL_CACHE and not packed and N > 0 and not needs_grad and not getattr(_cache, "disabled", False))
     key = None
     if needs_grad:
         _cache.entry = None  # a training step: do not keep the last eval image's records alive
