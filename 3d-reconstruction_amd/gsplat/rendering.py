@@ -240,18 +240,31 @@ def rasterization(
     meta: Dict = _Meta()
     packed_index = None
     hook = means2d
+    pack = None
     if packed:
-        # gsplat's packed layout for `meta` (render-only in the reference: SURVEY.md section 8(a) note on packed)
-        camera_ids, gaussian_ids, radii_p, means2d_p, depths_p, conics_p, packed_index = _pack_meta(
-            splats, means2d, radii)
-        hook = means2d_p
-        meta.update({"camera_ids": camera_ids, "gaussian_ids": gaussian_ids, "radii": radii_p, "means2d": means2d_p,
-                     "depths": depths_p, "conics": conics_p,
-                     "opacities": splats.detach().reshape(-1, B.GS_REC)[packed_index, 5]})
+        # gsplat's packed layout for `meta` (A.7; render-only in the reference: SURVEY.md section 8(a) note on packed).
+        # The rasterizer itself always works on the dense [C,N] records; the CSR arrays are a compaction of them.
+        def pack(_memo={}):
+            if not _memo:
+                camera_ids, gaussian_ids, radii_p, means2d_p, depths_p, conics_p, packed_index, cum = _pack_meta(
+                    splats, means2d, radii)
+                _memo.update({"camera_ids": camera_ids, "gaussian_ids": gaussian_ids, "radii": radii_p,
+                              "means2d": means2d_p, "depths": depths_p, "conics": conics_p, "_index": packed_index,
+                              "_cum": cum,
+                              "opacities": splats.detach().reshape(-1, B.GS_REC)[packed_index, 5]})
+            return _memo
+
+        if needs_grad:  # the packed means2d must be on the autograd path before the rasterizer runs
+            hook, packed_index = pack()["means2d"], pack()["_index"]
     render_colors, render_alphas, isect_ids, flatten_ids, isect_offsets, last_ids = W._RasterizeSplats.apply(
         splats, hook, tiles_per_gauss, bg, width, height, tile_size, channels, ed, absgrad, packed_index)
     meta._front_sort = W.take_front_sort()
     state = W.take_raster_state()
+    if packed:
+        # without gradients nothing upstream needs the CSR arrays: build them when `meta` is first asked for one
+        for k in ("camera_ids", "gaussian_ids", "radii", "means2d", "depths", "conics", "opacities"):
+            meta[k] = None
+            meta._thunks[k] = (lambda k=k: pack()[k])
 
     if not packed:
         sd = splats.detach()
@@ -262,6 +275,18 @@ def rasterization(
         "flatten_ids": flatten_ids, "isect_offsets": isect_offsets, "last_ids": last_ids,
         "width": width, "height": height, "tile_size": tile_size, "n_cameras": C,
     })
+    if packed:
+        # A.7: in packed mode flatten_ids index the packed rows (the rank of the dense row among the visible ones)
+        fs = meta._front_sort
+
+        def packed_flatten_ids():
+            if fs is not None:
+                fs.finalize()
+            return pack()["_cum"][flatten_ids.long()].to(torch.int32)
+
+        meta._thunks["flatten_ids"] = packed_flatten_ids
+        meta["tiles_per_gauss"] = None
+        meta._thunks["tiles_per_gauss"] = lambda: tiles_per_gauss.reshape(-1)[pack()["_index"]]
     if use_cache and state is not None:
         # a plain-dict snapshot of the call-independent entries (reading dict.items of the base class: no completion)
         _cache.entry = {"key": key, "state": state, "pins": (means, quats, scales, colors),
@@ -297,4 +322,4 @@ def _pack_meta(splats: Tensor, means2d: Tensor, radii: Tensor):
         means2d_p = means2d.reshape(-1, 2)[packed_index]
     else:
         means2d_p = m2d_p
-    return camera_ids, gaussian_ids, radii_p, means2d_p, depths_p, conics_p, packed_index
+    return camera_ids, gaussian_ids, radii_p, means2d_p, depths_p, conics_p, packed_index, cum

@@ -236,6 +236,12 @@ def test_config5_packed_render_only(gpu_device):
     assert torch.equal(meta["radii"], meta_u["radii"][vis])
     assert torch.equal(meta["means2d"], meta_u["means2d"][vis])
     assert torch.equal(meta["depths"], meta_u["depths"][vis])
+    assert torch.equal(meta["opacities"], meta_u["opacities"][vis])
+    assert torch.equal(meta["tiles_per_gauss"], meta_u["tiles_per_gauss"][vis])
+    # A.7: packed flatten_ids index the packed rows
+    assert meta["flatten_ids"].dtype == torch.int32
+    assert torch.equal(flat[meta["flatten_ids"].long()], meta_u["flatten_ids"].long())
+    assert torch.equal(meta["isect_ids"], meta_u["isect_ids"])
     _check_integer_stages(meta_u, C)
     cols = _sh_colors(p["means"], p["colors"], vm, 3).reshape(-1, 3)
     bad = _sampled_pixels_fp64(meta_u, cols, rc, ra, 150, ed=False, seed=2)
