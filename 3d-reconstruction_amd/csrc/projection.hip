@@ -154,16 +154,22 @@ __global__ __launch_bounds__(256) void projection_fwd_kernel(
     const float* __restrict__ scales, const float* __restrict__ opacities, const float* __restrict__ viewmats,
     const float* __restrict__ Ks, const float* __restrict__ campos, const float* __restrict__ colors,
     int32_t* __restrict__ radii, float* __restrict__ means2d, float* __restrict__ splats,
-    int32_t* __restrict__ tiles_per_gauss) {
+    int32_t* __restrict__ tiles_per_gauss, const float* __restrict__ covars) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= p.N) return;
   const float mu[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
-  const float q[4] = {quats[4 * n], quats[4 * n + 1], quats[4 * n + 2], quats[4 * n + 3]};
-  const float sc[3] = {scales[3 * n], scales[3 * n + 1], scales[3 * n + 2]};
   const float opac = opacities[n];
-  float Rq[9], qn[4], inv_norm, S[6];
-  quat_to_rot(q, Rq, qn, inv_norm);
-  covar3d(Rq, sc, S);
+  float S[6];
+  if (covars) {  // precomputed world covariances (gsplat `covars=`), upper triangle {xx,xy,xz,yy,yz,zz}
+#pragma unroll
+    for (int i = 0; i < 6; ++i) S[i] = covars[6 * n + i];
+  } else {
+    const float q[4] = {quats[4 * n], quats[4 * n + 1], quats[4 * n + 2], quats[4 * n + 3]};
+    const float sc[3] = {scales[3 * n], scales[3 * n + 1], scales[3 * n + 2]};
+    float Rq[9], qn[4], inv_norm;
+    quat_to_rot(q, Rq, qn, inv_norm);
+    covar3d(Rq, sc, S);
+  }
   const float W = (float)p.width, H = (float)p.height;
   const float ts = (float)p.tile_size;
 
@@ -255,18 +261,26 @@ __global__ __launch_bounds__(256, 2) void projection_bwd_kernel(
     const int32_t* __restrict__ radii, const float* __restrict__ splats, const float* __restrict__ v_means2d,
     int64_t ld_vm2, const float* __restrict__ v_splats, float* __restrict__ v_means, float* __restrict__ v_quats,
     float* __restrict__ v_scales, float* __restrict__ v_opacities, float* __restrict__ v_colors,
-    float* __restrict__ v_viewmats, float* __restrict__ v_campos) {
+    float* __restrict__ v_viewmats, float* __restrict__ v_campos, const float* __restrict__ covars,
+    float* __restrict__ v_covars) {
   constexpr int NB = (CMODE == GS_COLOR_SH) ? (DEG + 1) * (DEG + 1) : 1;
   const int n_raw = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = n_raw < p.N;
   const int n = live ? n_raw : p.N - 1;  // keep whole waves alive for the VIEWGRAD reductions
   const float mu[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
-  const float q[4] = {quats[4 * n], quats[4 * n + 1], quats[4 * n + 2], quats[4 * n + 3]};
-  const float sc[3] = {scales[3 * n], scales[3 * n + 1], scales[3 * n + 2]};
   const float opac = opacities[n];
-  float Rq[9], qn[4], inv_norm, S[6];
-  quat_to_rot(q, Rq, qn, inv_norm);
-  covar3d(Rq, sc, S);
+  float Rq[9], qn[4], inv_norm = 0.f, S[6];
+  float sc[3] = {0.f, 0.f, 0.f};
+  if (covars) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) S[i] = covars[6 * n + i];
+  } else {
+    const float q[4] = {quats[4 * n], quats[4 * n + 1], quats[4 * n + 2], quats[4 * n + 3]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sc[i] = scales[3 * n + i];
+    quat_to_rot(q, Rq, qn, inv_norm);
+    covar3d(Rq, sc, S);
+  }
   const float W = (float)p.width, H = (float)p.height;
 
   float v_mu[3] = {0.f, 0.f, 0.f};
@@ -474,6 +488,20 @@ __global__ __launch_bounds__(256, 2) void projection_bwd_kernel(
   }
   if (!live) return;
 
+  if (covars) {
+    // gradient w.r.t. the 6 upper-triangle parameters: an off-diagonal one sits at (i,j) and (j,i) of Sigma
+    v_covars[6 * n + 0] = v_S[0]; v_covars[6 * n + 1] = 2.f * v_S[1]; v_covars[6 * n + 2] = 2.f * v_S[2];
+    v_covars[6 * n + 3] = v_S[3]; v_covars[6 * n + 4] = 2.f * v_S[4]; v_covars[6 * n + 5] = v_S[5];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v_means[3 * n + k] = v_mu[k];
+    v_opacities[n] = v_op;
+    if constexpr (CMODE == GS_COLOR_N) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (k < p.color_dim) v_colors[(int64_t)n * p.color_dim + k] = v_col[k];
+    }
+    return;
+  }
+
   // ---- Sigma = M M^T, M = Rq diag(s):  v_M = 2 v_S M
   float M[9], vM[9];
 #pragma unroll
@@ -544,18 +572,20 @@ static int check_params(const gs_proj_params* p) {
 
 }  // namespace gs
 
-#define GS_FWD_ARGS *p, means, quats, scales, opacities, viewmats, Ks, campos, colors, radii, means2d, splats, tiles_per_gauss
+#define GS_FWD_ARGS *p, means, quats, scales, opacities, viewmats, Ks, campos, colors, radii, means2d, splats, tiles_per_gauss, covars
 #define GS_FWD_LAUNCH(CM, DG) hipLaunchKernelGGL((gs::projection_fwd_kernel<CM, DG>), grid, block, 0, s, GS_FWD_ARGS)
 
 extern "C" int gs_projection_fwd(const gs_proj_params* p, const float* means, const float* quats,
                                  const float* scales, const float* opacities, const float* viewmats,
                                  const float* Ks, const float* campos, const float* colors, int32_t* radii,
-                                 float* means2d, float* splats, int32_t* tiles_per_gauss, void* stream) {
+                                 float* means2d, float* splats, int32_t* tiles_per_gauss, const float* covars,
+                                 void* stream) {
   int st = gs::check_params(p);
   if (st != GS_OK) return st;
   if (p->N == 0) return GS_OK;
-  if (!means || !quats || !scales || !opacities || !viewmats || !Ks || !radii || !means2d || !splats || !tiles_per_gauss)
+  if (!means || !opacities || !viewmats || !Ks || !radii || !means2d || !splats || !tiles_per_gauss)
     return GS_ERR_INVALID_ARG;
+  if (!covars && (!quats || !scales)) return GS_ERR_INVALID_ARG;
   if (p->color_mode != GS_COLOR_NONE && !colors) return GS_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)gs::ceil_div(p->N, 256)), block(256);
@@ -576,7 +606,7 @@ extern "C" int gs_projection_fwd(const gs_proj_params* p, const float* means, co
   return GS_OK;
 }
 
-#define GS_BWD_ARGS *p, means, quats, scales, opacities, viewmats, Ks, campos, colors, radii, splats, v_means2d, ld_v_means2d, v_splats, v_means, v_quats, v_scales, v_opacities, v_colors, v_viewmats, v_campos
+#define GS_BWD_ARGS *p, means, quats, scales, opacities, viewmats, Ks, campos, colors, radii, splats, v_means2d, ld_v_means2d, v_splats, v_means, v_quats, v_scales, v_opacities, v_colors, v_viewmats, v_campos, covars, v_covars
 #define GS_BWD_LAUNCH(CM, DG)                                                                              \
   do {                                                                                                     \
     if (v_viewmats)                                                                                        \
@@ -591,13 +621,15 @@ extern "C" int gs_projection_bwd(const gs_proj_params* p, const float* means, co
                                  const int32_t* radii, const float* splats, const float* v_means2d,
                                  int64_t ld_v_means2d, const float* v_splats, float* v_means, float* v_quats,
                                  float* v_scales, float* v_opacities, float* v_colors, float* v_viewmats,
-                                 float* v_campos, void* stream) {
+                                 float* v_campos, const float* covars, float* v_covars, void* stream) {
   int st = gs::check_params(p);
   if (st != GS_OK) return st;
   if (p->N == 0) return GS_OK;
-  if (!means || !quats || !scales || !opacities || !viewmats || !Ks || !radii || !splats || !v_means2d ||
-      !v_splats || !v_means || !v_quats || !v_scales || !v_opacities || ld_v_means2d < 2)
+  if (!means || !opacities || !viewmats || !Ks || !radii || !splats || !v_means2d || !v_splats || !v_means ||
+      !v_opacities || ld_v_means2d < 2)
     return GS_ERR_INVALID_ARG;
+  if (covars ? !v_covars : (!quats || !scales || !v_quats || !v_scales)) return GS_ERR_INVALID_ARG;
+  if (covars && p->color_mode == GS_COLOR_SH) return GS_ERR_UNSUPPORTED;  // SH colours go through gs_sh_fwd/bwd then
   if (p->color_mode != GS_COLOR_NONE && (!colors || !v_colors)) return GS_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)gs::ceil_div(p->N, 256)), block(256);

@@ -39,8 +39,8 @@ _P = c_void_p
 _SIGNATURES = {
     "gs_version": (ctypes.c_int, []),
     "gs_error_string": (c_char_p, [ctypes.c_int]),
-    "gs_projection_fwd": (ctypes.c_int, [POINTER(ProjParams)] + [_P] * 12 + [_P]),
-    "gs_projection_bwd": (ctypes.c_int, [POINTER(ProjParams)] + [_P] * 11 + [c_int64] + [_P] * 8 + [_P]),
+    "gs_projection_fwd": (ctypes.c_int, [POINTER(ProjParams)] + [_P] * 13 + [_P]),
+    "gs_projection_bwd": (ctypes.c_int, [POINTER(ProjParams)] + [_P] * 11 + [c_int64] + [_P] * 10 + [_P]),
     "gs_sh_fwd": (ctypes.c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
     "gs_sh_bwd": (ctypes.c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "gs_exclusive_scan_workspace_bytes": (c_int64, [c_int64]),

@@ -106,10 +106,15 @@ class _ProjectSplats(torch.autograd.Function):
     (+ radii, tiles_per_gauss, non-differentiable)."""
 
     @staticmethod
-    def forward(ctx, means, quats, scales, opacities, colors, viewmats, Ks, campos, params: B.ProjParams):
-        dev = B.require_gpu(means, quats, scales, opacities, colors, viewmats, Ks, campos)
+    def forward(ctx, means, quats, scales, opacities, colors, viewmats, Ks, campos, params: B.ProjParams,
+                covars=None):
+        dev = B.require_gpu(means, quats, scales, opacities, colors, viewmats, Ks, campos, covars)
         N, C = params.N, params.C
-        means, quats, scales, opacities = B.f32c(means), B.f32c(quats), B.f32c(scales), B.f32c(opacities)
+        means, opacities = B.f32c(means), B.f32c(opacities)
+        if covars is not None:  # [N,6] upper triangle; quats / scales are not used
+            covars, quats, scales = B.f32c(covars), None, None
+        else:
+            quats, scales = B.f32c(quats), B.f32c(scales)
         viewmats, Ks = B.f32c(viewmats), B.f32c(Ks)
         colors = B.f32c(colors) if colors is not None else None
         campos = B.f32c(campos) if campos is not None else None
@@ -122,20 +127,26 @@ class _ProjectSplats(torch.autograd.Function):
             B.check(B.lib().gs_projection_fwd(
                 ctypes.byref(params), B.ptr(means), B.ptr(quats), B.ptr(scales), B.ptr(opacities), B.ptr(viewmats),
                 B.ptr(Ks), B.ptr(campos), B.ptr(colors), B.ptr(radii), B.ptr(means2d), B.ptr(splats), B.ptr(tiles),
-                B.stream_handle(dev)), "gs_projection_fwd")
+                B.ptr(covars), B.stream_handle(dev)), "gs_projection_fwd")
         ctx.params = params
         ctx.has_colors = colors is not None
         ctx.has_campos = campos is not None
+        ctx.has_covars = covars is not None
         empty = torch.empty(0, device=dev)
-        ctx.save_for_backward(means, quats, scales, opacities, colors if colors is not None else empty, viewmats, Ks,
-                              campos if campos is not None else empty, radii, splats)
+        ctx.save_for_backward(means, quats if quats is not None else empty, scales if scales is not None else empty,
+                              opacities, colors if colors is not None else empty, viewmats, Ks,
+                              campos if campos is not None else empty, radii, splats,
+                              covars if covars is not None else empty)
         ctx.mark_non_differentiable(radii, tiles)
         ctx.set_materialize_grads(False)
         return splats, means2d, radii, tiles
 
     @staticmethod
     def backward(ctx, v_splats, v_means2d, _v_radii, _v_tiles):
-        means, quats, scales, opacities, colors, viewmats, Ks, campos, radii, splats = ctx.saved_tensors
+        means, quats, scales, opacities, colors, viewmats, Ks, campos, radii, splats, covars = ctx.saved_tensors
+        covars = covars if ctx.has_covars else None
+        if covars is not None:
+            quats = scales = None
         p = ctx.params
         dev = means.device
         N, C = p.N, p.C
@@ -153,8 +164,9 @@ class _ProjectSplats(torch.autograd.Function):
             v_means2d = B.f32c(v_means2d)
         ld = v_means2d.stride(1) if N > 0 else 2
         v_means = torch.empty_like(means)
-        v_quats = torch.empty_like(quats)
-        v_scales = torch.empty_like(scales)
+        v_quats = torch.empty_like(quats) if quats is not None else None
+        v_scales = torch.empty_like(scales) if scales is not None else None
+        v_covars = torch.empty_like(covars) if covars is not None else None
         v_opac = torch.empty_like(opacities)
         v_colors = torch.empty_like(colors) if colors is not None else None
         need_vm = ctx.needs_input_grad[5] or ctx.needs_input_grad[7]
@@ -165,11 +177,14 @@ class _ProjectSplats(torch.autograd.Function):
                 ctypes.byref(p), B.ptr(means), B.ptr(quats), B.ptr(scales), B.ptr(opacities), B.ptr(viewmats),
                 B.ptr(Ks), B.ptr(campos), B.ptr(colors), B.ptr(radii), B.ptr(splats), v_means2d.data_ptr(), ld,
                 B.ptr(v_splats), B.ptr(v_means), B.ptr(v_quats), B.ptr(v_scales), B.ptr(v_opac), B.ptr(v_colors),
-                B.ptr(v_viewmats), B.ptr(v_campos), B.stream_handle(dev)), "gs_projection_bwd")
+                B.ptr(v_viewmats), B.ptr(v_campos), B.ptr(covars), B.ptr(v_covars), B.stream_handle(dev)),
+                "gs_projection_bwd")
         g = ctx.needs_input_grad
-        return (v_means if g[0] else None, v_quats if g[1] else None, v_scales if g[2] else None,
+        return (v_means if g[0] else None, v_quats if (g[1] and v_quats is not None) else None,
+                v_scales if (g[2] and v_scales is not None) else None,
                 v_opac if g[3] else None, v_colors if (g[4] and v_colors is not None) else None,
-                v_viewmats if g[5] else None, None, v_campos if (g[7] and v_campos is not None) else None, None)
+                v_viewmats if g[5] else None, None, v_campos if (g[7] and v_campos is not None) else None, None,
+                v_covars if (len(g) > 9 and g[9] and v_covars is not None) else None)
 
 
 # ----------------------------------------------------------------------------- integer stages
@@ -243,6 +258,12 @@ def isect_tiles_from_splats(splats: Tensor, tiles_per_gauss: Tensor, tile_width:
 
 
 _tls = threading.local()
+
+
+def set_absgrad_accumulate(on: bool) -> None:
+    """While on, rasterizer passes created on this thread ADD their abs-gradient to `means2d.absgrad` in backward
+    instead of replacing it (several passes sharing one means2d: the >4-channel path)."""
+    _tls.absgrad_accumulate = bool(on)
 
 
 def take_front_sort():
@@ -463,6 +484,7 @@ class _RasterizeSplats(torch.autograd.Function):
                                                      None, B.stream_handle(dev)), "gs_raster_tile_order")
         ctx.tile_order = order_bwd
         ctx.geom = (C, N, width, height, tile_size, channels, int(ed), bool(absgrad))
+        ctx.absgrad_accumulate = getattr(_tls, "absgrad_accumulate", False)
         ctx.has_bg = bg is not None
         ctx.has_packed = packed_index is not None
         empty = torch.empty(0, device=dev)
@@ -501,7 +523,10 @@ class _RasterizeSplats(torch.autograd.Function):
             if absgrad:
                 # same attribute contract as gsplat: read by BasicTrainer.postprocess_per_train_step
                 # (/root/reference/3D-Reconstruction-main/models/trainers/base.py:282)
-                means2d.absgrad = v_splats[..., 10:12]
+                ag = v_splats[..., 10:12]
+                if ctx.absgrad_accumulate and getattr(means2d, "absgrad", None) is not None:
+                    ag = means2d.absgrad + ag
+                means2d.absgrad = ag
         v_bg = None
         if ctx.has_bg and ctx.needs_input_grad[3]:
             vc = v_rc

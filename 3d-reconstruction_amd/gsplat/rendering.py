@@ -100,8 +100,9 @@ def clear_cache() -> None:
     _cache.entry = None
 
 
-def _cache_key(means, quats, scales, colors, viewmats, Ks, scalars):
-    tens = tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype, str(t.device)) for t in (means, quats, scales, colors))
+def _cache_key(gaussian_tensors, viewmats, Ks, scalars):
+    tens = tuple(None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype, str(t.device))
+                 for t in gaussian_tensors)
     cams = torch.cat([viewmats.detach().reshape(-1).float(), Ks.detach().reshape(-1).float()]).cpu().numpy().tobytes()
     return tens + (cams,) + scalars
 
@@ -143,15 +144,20 @@ def rasterization(
     N = means.shape[0]
     C = viewmats.shape[0]
     assert means.shape == (N, 3), means.shape
-    assert quats.shape == (N, 4), quats.shape
-    assert scales.shape == (N, 3), scales.shape
+    if covars is None:
+        assert quats.shape == (N, 4), quats.shape
+        assert scales.shape == (N, 3), scales.shape
+    else:
+        # gsplat: precomputed world covariances [N,3,3] (or their upper triangle [N,6]); quats / scales are ignored
+        assert covars.shape in ((N, 3, 3), (N, 6)), covars.shape
+        if covars.dim() == 3:
+            covars = covars.reshape(N, 9)[:, [0, 1, 2, 4, 5, 8]]
+        quats = scales = None
     assert opacities.shape == (N,), opacities.shape
     assert viewmats.shape == (C, 4, 4), viewmats.shape
     assert Ks.shape == (C, 3, 3), Ks.shape
     assert render_mode in ["RGB", "D", "ED", "RGB+D", "RGB+ED"], render_mode
     assert rasterize_mode in ["classic", "antialiased"], rasterize_mode
-    if covars is not None:
-        raise NotImplementedError("gsplat (MI355X build): precomputed `covars` are not supported")
     if distributed:
         raise NotImplementedError("gsplat (MI355X build): use gsplat.distributed (camera-sharded DP) instead")
     if sparse_grad:
@@ -180,7 +186,7 @@ def rasterization(
         color_dim = colors.shape[-1]
         color_mode = B.GS_COLOR_N if colors.dim() == 2 else B.GS_COLOR_CN
         col_in = colors
-    elif colors.dim() == 3:
+    elif colors.dim() == 3 and covars is None:
         color_mode, color_dim, col_in = B.GS_COLOR_SH, 3, colors
         sh_K = colors.shape[-2]
         # camera centres feed the SH view directions; when the poses are being optimised they stay an autograd
@@ -188,16 +194,19 @@ def rasterization(
         campos = W._camera_centers(viewmats) if (viewmats.requires_grad and torch.is_grad_enabled()) else None
     else:
         # per-camera SH coefficients [C,N,K,3]: evaluate with the standalone op, then feed [C,N,3]
+        # (also SH coefficients [N,K,3] together with `covars`: the fused kernel builds Sigma from quats / scales)
         cp = W._camera_centers(viewmats)
         dirs = means[None, :, :] - cp[:, None, :]
-        col_in = torch.clamp_min(W.spherical_harmonics(sh_degree, dirs, colors) + 0.5, 0.0)
+        shs = colors if colors.dim() == 4 else colors[None].expand(C, -1, -1, -1)
+        col_in = torch.clamp_min(W.spherical_harmonics(sh_degree, dirs, shs) + 0.5, 0.0)
         color_mode, color_dim = B.GS_COLOR_CN, 3
         sh_degree = None
     channels = color_dim + (1 if want_depth else 0)
     if channels > 4:
-        raise NotImplementedError(
-            f"gsplat (MI355X build): {channels} render channels requested; this build rasterizes at most 4 "
-            "(RGB + depth) per call")
+        assert sh_degree is None
+        return _rasterization_chunked(means, quats, scales, opacities, col_in, viewmats, Ks, width, height, near_plane,
+                                      far_plane, radius_clip, eps2d, packed, tile_size, backgrounds, want_depth, ed,
+                                      absgrad, rasterize_mode, covars)
     if backgrounds is not None:
         assert backgrounds.shape == (C, color_dim), backgrounds.shape
         bg = backgrounds
@@ -211,13 +220,14 @@ def rasterization(
     # ---- eval re-render cache (see EVAL_CACHE above)
     geom = (C, N, width, height, tile_size, channels, ed)
     needs_grad = torch.is_grad_enabled() and any(
-        t is not None and t.requires_grad for t in (means, quats, scales, opacities, colors, viewmats, backgrounds))
+        t is not None and t.requires_grad
+        for t in (means, quats, scales, opacities, colors, viewmats, backgrounds, covars))
     use_cache = (EVAL_CACHE and not packed and N > 0 and not needs_grad and not getattr(_cache, "disabled", False))
     key = None
     if needs_grad:
         _cache.entry = None  # a training step: do not keep the last eval image's records alive
     elif use_cache:
-        key = _cache_key(means, quats, scales, colors, viewmats, Ks,
+        key = _cache_key((means, quats, scales, colors, covars), viewmats, Ks,
                          (geom, float(near_plane), float(far_plane), float(radius_clip), float(eps2d), sh_degree,
                           render_mode, rasterize_mode))
         ent = getattr(_cache, "entry", None)
@@ -234,7 +244,7 @@ def rasterization(
     params = W._make_params(N, C, width, height, tile_size, eps2d, near_plane, far_plane, radius_clip,
                             rasterize_mode == "antialiased", color_mode, color_dim, sh_degree, sh_K, want_depth)
     splats, means2d, radii, tiles_per_gauss = W._ProjectSplats.apply(
-        means, quats, scales, opacities, col_in, viewmats, Ks, campos, params)
+        means, quats, scales, opacities, col_in, viewmats, Ks, campos, params, covars)
 
     TW, TH = math.ceil(width / tile_size), math.ceil(height / tile_size)
     meta: Dict = _Meta()
@@ -289,9 +299,66 @@ def rasterization(
         meta._thunks["tiles_per_gauss"] = lambda: tiles_per_gauss.reshape(-1)[pack()["_index"]]
     if use_cache and state is not None:
         # a plain-dict snapshot of the call-independent entries (reading dict.items of the base class: no completion)
-        _cache.entry = {"key": key, "state": state, "pins": (means, quats, scales, colors),
+        _cache.entry = {"key": key, "state": state, "pins": (means, quats, scales, colors, covars),
                         "meta": {k: v for k, v in dict.items(meta) if k not in ("last_ids", "opacities")}}
     return render_colors, render_alphas, meta
+
+
+def _rasterization_chunked(means, quats, scales, opacities, colors, viewmats, Ks, width, height, near_plane, far_plane,
+                           radius_clip, eps2d, packed, tile_size, backgrounds, want_depth, ed, absgrad, rasterize_mode,
+                           covars=None):
+    """More than 4 render channels (feature rendering; gsplat's `channel_chunk` loop, A.0 step 7).  The splat record
+    carries 4 channels, so: ONE projection (records with the depth channel only), then one rasterizer pass per group
+    of 4 channels over a copy of the records with that group's colours written in.  All passes share `means2d` (its
+    .grad / .absgrad accumulate over the groups, as in gsplat) and the alphas are those of the first pass.  Every pass
+    repeats the tile sort -- a compatibility path, not a fast one; the reference never asks for it."""
+    if packed:
+        raise NotImplementedError("gsplat (MI355X build): packed=True with more than 4 render channels")
+    N, C = means.shape[0], viewmats.shape[0]
+    D = colors.shape[-1]
+    cols = colors[None].expand(C, N, D) if colors.dim() == 2 else colors
+    params = W._make_params(N, C, width, height, tile_size, eps2d, near_plane, far_plane, radius_clip,
+                            rasterize_mode == "antialiased", B.GS_COLOR_NONE, 0, None, 0, True)
+    splats, means2d, radii, tiles_per_gauss = W._ProjectSplats.apply(
+        means, quats, scales, opacities, None, viewmats, Ks, None, params, covars)
+    n_ch = D + (1 if want_depth else 0)
+    bg_all = None
+    if backgrounds is not None:
+        assert backgrounds.shape == (C, D), backgrounds.shape
+        bg_all = backgrounds
+        if want_depth:
+            bg_all = torch.cat([backgrounds, torch.zeros(C, 1, device=backgrounds.device, dtype=backgrounds.dtype)], -1)
+    outs, alphas, meta = [], None, _Meta()
+    W.set_absgrad_accumulate(True)
+    try:
+        for c0 in range(0, n_ch, 4):
+            c1 = min(c0 + 4, n_ch)
+            rec = splats.clone()
+            k_col = min(c1, D) - c0  # colour channels of this group; the depth channel (record slot 6) may follow
+            if k_col > 0:
+                rec[..., 6:6 + k_col] = cols[..., c0:c0 + k_col]
+            if c1 > D:
+                rec[..., 6 + max(k_col, 0)] = splats[..., 6]
+            last = c1 == n_ch
+            rc, ra, isect_ids, flatten_ids, isect_offsets, last_ids = W._RasterizeSplats.apply(
+                rec, means2d, tiles_per_gauss, bg_all[:, c0:c1].contiguous() if bg_all is not None else None, width,
+                height, tile_size, c1 - c0, bool(ed and last), absgrad, None)
+            fs = W.take_front_sort()
+            W.take_raster_state()
+            outs.append(rc)
+            if alphas is None:
+                alphas = ra
+                sd = splats.detach()
+                meta.update({"camera_ids": None, "gaussian_ids": None, "radii": radii, "means2d": means2d,
+                             "depths": sd[..., 10], "conics": sd[..., 2:5], "opacities": sd[..., 5],
+                             "tile_width": math.ceil(width / tile_size), "tile_height": math.ceil(height / tile_size),
+                             "tiles_per_gauss": tiles_per_gauss, "isect_ids": isect_ids, "flatten_ids": flatten_ids,
+                             "isect_offsets": isect_offsets, "last_ids": last_ids, "width": width, "height": height,
+                             "tile_size": tile_size, "n_cameras": C})
+                meta._front_sort = fs
+    finally:
+        W.set_absgrad_accumulate(False)
+    return torch.cat(outs, dim=-1), alphas, meta
 
 
 def _pack_meta(splats: Tensor, means2d: Tensor, radii: Tensor):

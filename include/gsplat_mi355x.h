@@ -87,6 +87,8 @@ int gs_projection_fwd(const gs_proj_params* p,
                       float* means2d,          /* out [C,N,2]                   */
                       float* splats,           /* out [C,N,16], rows with radii==0 untouched */
                       int32_t* tiles_per_gauss,/* out [C,N]                     */
+                      const float* covars,     /* [N,6] world covariances {xx,xy,xz,yy,yz,zz} (gsplat `covars=`) or NULL;
+                                                  when given, quats / scales are ignored and may be NULL */
                       void* stream);
 
 int gs_projection_bwd(const gs_proj_params* p,
@@ -105,6 +107,8 @@ int gs_projection_bwd(const gs_proj_params* p,
                       float* v_colors,         /* out, shape of `colors`, may be NULL */
                       float* v_viewmats,       /* out [C,4,4], PRE-ZEROED, may be NULL */
                       float* v_campos,         /* out [C,3],   PRE-ZEROED, may be NULL */
+                      const float* covars,     /* [N,6] or NULL, as in the forward (not with GS_COLOR_SH) */
+                      float* v_covars,         /* out [N,6] when covars is given (v_quats / v_scales unused) */
                       void* stream);
 
 /* ---- spherical_harmonics --------------------------------------------------------------------- */

@@ -137,3 +137,32 @@ def test_camera_centers_and_saved_tensor_identity():
     hook.retain_grad()
     F.apply(a, hook).sum().backward()
     assert hasattr(hook, "absgrad") and hook.grad is not None
+
+
+def test_meta_dict_completes_lazy_entries_on_read():
+    """`meta` of rasterization(): front-sorted isect arrays are completed, and deferred entries built, on first read."""
+    from gsplat.rendering import _Meta
+
+    class FakeFront:
+        def __init__(self):
+            self.calls = 0
+
+        def finalize(self):
+            self.calls += 1
+
+    fs = FakeFront()
+    m = _Meta({"isect_ids": "ids", "flatten_ids": "flat", "radii": None, "width": 7})
+    m._front_sort = fs
+    built = []
+    m._thunks["radii"] = lambda: built.append(1) or "radii!"
+    assert m["width"] == 7 and fs.calls == 0 and not built      # unrelated keys trigger nothing
+    assert "flatten_ids" in m and fs.calls == 0                   # membership does not read
+    assert m["radii"] == "radii!" and built == [1] and fs.calls == 0
+    assert m["radii"] == "radii!" and built == [1]                # built once
+    assert m.get("flatten_ids") == "flat" and fs.calls == 1
+    assert m["isect_ids"] == "ids" and fs.calls == 1              # completed once
+    m2 = _Meta({"isect_ids": 1, "x": None})
+    m2._front_sort = fs
+    m2._thunks["x"] = lambda: 5
+    assert dict(m2.items()) == {"isect_ids": 1, "x": 5} and fs.calls == 2
+    assert m2.copy() == {"isect_ids": 1, "x": 5}
