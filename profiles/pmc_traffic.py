@@ -25,7 +25,7 @@ KERNELS = {  # bench.py entry-point label -> substring(s) of the HIP kernel name
     "gs_isect_bin_count": ["gs::isect_bin_kernel<false>"],
     "gs_isect_bin_scatter": ["gs::isect_bin_kernel<true>"],
     "gs_isect_bin_offsets": ["gs::bin_slice_prefix_kernel", "gs::bin_offsets_kernel"],
-    "gs_isect_tile_sort": ["gs::tile_sort_kernel"],
+    "gs_isect_tile_sort": ["gs::tile_sort_kernel", "gs::tile_sort_front_kernel"],
     "gs_rasterize_fwd": ["gs::rasterize_fwd_kernel"],
     "gs_rasterize_bwd": ["gs::rasterize_bwd_kernel"],
 }
@@ -41,7 +41,10 @@ def per_kernel(directory, counter):
                     continue
                 tot[row["Kernel_Name"]] += float(row["Counter_Value"])
                 cnt[row["Kernel_Name"]] += 1
-    return {k: (cnt[k], tot[k] / cnt[k]) for k in tot}
+    # per STEP, not per launch: an entry point may launch a kernel more than once per step (size classes of the tile
+    # sort, the rasterizer's redo pass), and the steps of the run are the launches of the once-per-step projection
+    steps = max([c for k, c in cnt.items() if "gs::projection_fwd_kernel" in k] or [1])
+    return {k: (cnt[k], tot[k] / (steps if "gs::" in k else cnt[k])) for k in tot}
 
 
 def main():
@@ -50,7 +53,7 @@ def main():
     rd = per_kernel(rd_dir, "FETCH_SIZE")
     wr = per_kernel(wr_dir, "WRITE_SIZE")
     out = {"gaussians": N, "cams": C, "height": H, "width": W,
-           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py, mean per launch; "
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py, mean per step of the entry point's launches; "
                      "FETCH_SIZE KiB x 1024 x 2 (gfx950 half-count correction), WRITE_SIZE KiB x 1024",
            "kernels": {}, "calibration": {}}
     for label, subs in KERNELS.items():
