@@ -61,6 +61,8 @@ _SIGNATURES = {
     "gs_rasterize_fwd": (ctypes.c_int, [c_int32] * 5 + [_P, _P, _P, c_int64, _P, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32, _P]),
     "gs_rasterize_bwd": (ctypes.c_int, [c_int32] * 5 + [_P, _P, _P, c_int64, _P, c_int32, _P, _P, _P, _P, _P, c_int32, _P, _P, _P]),
     "gs_raster_tile_order": (ctypes.c_int, [c_int32, _P, c_int64, _P, _P, _P, _P]),
+    "gs_densify_accumulate": (ctypes.c_int, [c_int32, c_int32, _P, _P, c_int64, c_float, c_float, c_float, c_int32,
+                                             _P, _P, _P, _P]),
     "gs_mark_visible": (ctypes.c_int, [c_int64, _P, _P, _P]),
     "gs_compact_visible": (ctypes.c_int, [c_int32, c_int32] + [_P] * 10 + [_P]),
 }

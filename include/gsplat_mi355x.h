@@ -272,6 +272,17 @@ int gs_compact_visible(int32_t C, int32_t N, const int32_t* radii, const int32_t
                        float* conics_packed,                          /* out [nnz,3] */
                        void* stream);
 
+/* ---- densification statistics (next to the path: SURVEY.md 8(f) rank 2) -------------------------- */
+/* One fused pass of BasicTrainer.postprocess_per_train_step's gradient scaling (R/models/trainers/base.py:279-297)
+ * + VanillaGaussians.after_train (R/models/gaussians/vanilla.py:154-182).  grad2d points at the 2-float screen-space
+ * gradient of row (c, n) with a row stride of `ld` floats (means2d.absgrad / .grad are views of the gradient record:
+ * ld = 16); scale_x = width / 2 * batch_size, scale_y = height / 2 * batch_size, inv_last_size = 1 / max(W, H).
+ * first != 0: initialise (grad_norm_sum = |grad| for every row, vis_counts = 1, max_2dsize from zero). */
+int gs_densify_accumulate(int32_t C, int32_t N, const int32_t* radii /* [C,N] */, const float* grad2d, int64_t ld,
+                          float scale_x, float scale_y, float inv_last_size, int32_t first,
+                          float* grad_norm_sum /* [N] in/out */, float* vis_counts /* [N] in/out */,
+                          float* max_2dsize /* [N] in/out */, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
