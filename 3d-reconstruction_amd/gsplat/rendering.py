@@ -379,10 +379,11 @@ def _pack_meta(splats: Tensor, means2d: Tensor, radii: Tensor):
     depths_p = torch.empty(nnz, device=dev, dtype=torch.float32)
     conics_p = torch.empty(nnz, 3, device=dev, dtype=torch.float32)
     with torch.cuda.device(dev):
-        B.check(B.lib().gs_compact_visible(C, N, B.ptr(radii), B.ptr(cum), B.ptr(splats.detach()),
-                                           B.ptr(means2d.detach()), B.ptr(camera_ids), B.ptr(gaussian_ids),
-                                           B.ptr(radii_p), B.ptr(m2d_p), B.ptr(depths_p), B.ptr(conics_p),
-                                           B.stream_handle(dev)), "gs_compact_visible")
+        if nnz > 0:  # (nothing visible: the empty outputs have no storage to point at)
+            B.check(B.lib().gs_compact_visible(C, N, B.ptr(radii), B.ptr(cum), B.ptr(splats.detach()),
+                                               B.ptr(means2d.detach()), B.ptr(camera_ids), B.ptr(gaussian_ids),
+                                               B.ptr(radii_p), B.ptr(m2d_p), B.ptr(depths_p), B.ptr(conics_p),
+                                               B.stream_handle(dev)), "gs_compact_visible")
     packed_index = camera_ids * N + gaussian_ids
     if means2d.requires_grad:
         # keep the packed means2d on the autograd path so that retain_grad()/.absgrad work as in gsplat

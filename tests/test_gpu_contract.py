@@ -196,3 +196,27 @@ def test_run_to_run_integer_determinism(gpu_device):
     for k in p0:
         frac, rel_l2, _ = close_report(f"rerun.v_{k}", p0[k].grad, p1[k].grad)
         assert rel_l2 < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("packed", [False, True])
+def test_nothing_visible(gpu_device, packed):
+    """Every Gaussian behind the camera: empty lists, background-only images, zero gradients, no error (found by
+    scratch/fuzz.py: the packed compaction was handed the empty outputs' null pointers)."""
+    import synth_scene
+    from gsplat.rendering import rasterization
+
+    dev = gpu_device
+    N, W, H = 300, 64, 48
+    g = synth_scene.make_gaussians(N, sh_degree=None, extent=5.0)
+    g["means"][:, 0] = -50.0 - g["means"][:, 0].abs()  # camera 0 of the rig looks along +x
+    p = {k: v.to(dev).requires_grad_(True) for k, v in g.items()}
+    vm, Ks = (t.to(dev) for t in synth_scene.make_cameras(1, W, H))
+    bg = torch.rand(1, 3, device=dev)
+    rc, ra, meta = rasterization(p["means"], p["quats"], p["scales"], p["opacities"], p["colors"], vm, Ks, W, H,
+                                 near_plane=0.1, packed=packed, render_mode="RGB+ED", absgrad=True, backgrounds=bg)
+    assert meta["flatten_ids"].numel() == 0 and int(ra.abs().sum()) == 0
+    assert torch.equal(rc[..., :3], bg.view(1, 1, 1, 3).expand(1, H, W, 3))
+    assert meta["radii"].numel() == (0 if packed else N)
+    (rc.sum() + ra.sum()).backward()
+    assert all(v.grad is not None and float(v.grad.abs().sum()) == 0.0 for v in p.values())
