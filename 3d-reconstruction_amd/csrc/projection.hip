@@ -458,32 +458,16 @@ __global__ __launch_bounds__(256, 2) void projection_bwd_kernel(
     constexpr int ROWS = (NB3 <= 48) ? 64 : 32;      // rows per round (LDS budget: 4 waves x ROWS x TS floats)
     __shared__ float s_t[4][ROWS * TS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* t = s_t[wave];  // private to the wave: LDS operations of one wave complete in order, no barrier needed
+    float* t = s_t[wave];  // private to the wave
     const int K3 = p.sh_K * 3;
 #pragma unroll 1
     for (int h = 0; h < 64 / ROWS; ++h) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
       if (lane / ROWS == h) {
 #pragma unroll
         for (int k = 0; k < NB3; ++k) t[(lane % ROWS) * TS + k] = v_col[k];
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
       const int row0 = n_raw - lane + ROWS * h;  // first Gaussian of this round
-      const int total = min(ROWS, p.N - row0) * K3;
-      float* base = v_colors + (int64_t)row0 * K3;
-      if (K3 == NB3) {
-        for (int m = lane; m < total; m += 64) base[m] = t[m + m / NB3];
-      } else {
-        const float inv_k3 = 1.f / (float)K3;
-        for (int m = lane; m < total; m += 64) {
-          int g = (int)(((float)m + 0.5f) * inv_k3);
-          int k = m - g * K3;
-          if (k < 0) { --g; k += K3; } else if (k >= K3) { ++g; k -= K3; }
-          base[m] = (k < NB3) ? t[g * TS + k] : 0.f;
-        }
-      }
+      wave_rows_store<NB3>(t, v_colors + (int64_t)row0 * K3, min(ROWS, p.N - row0), K3, lane);
     }
   }
   if (!live) return;

@@ -1,15 +1,27 @@
-// Standalone spherical_harmonics forward/backward (HBM-bound: 12+12K B read, 12 B written per row).
-// One thread per (flattened) Gaussian row; each lane streams its own contiguous K*12-byte
-// coefficient block, so every fetched line is fully consumed.
+// Standalone spherical_harmonics forward/backward (HBM-bound: 12+12K B read, 12 B written per row; the reference calls
+// it once per Gaussian class and step: models/gaussians/vanilla.py:369, models/nodes/rigid.py:486, ...).
+// One thread per (flattened) Gaussian row.  The backward's coefficient-gradient rows are dense (masked-out rows are
+// zeros) and leave wave-cooperatively through LDS as contiguous 256-B wave rows (sh_math.hpp, wave_rows_store):
+// 3.6 -> 6.4 TB/s at 3 M rows, K = 16.
 #include "sh_math.hpp"
 
 namespace gs {
+
+template <int DEG>
+struct ShTile {
+  static constexpr int NB3 = (DEG + 1) * (DEG + 1) * 3;
+  static constexpr int ROWS = (NB3 <= 48) ? 64 : 32;  // rows per round: 4 waves x ROWS x (NB3 + 1) floats of LDS
+  static constexpr int FLOATS = ROWS * (NB3 + 1);
+};
 
 template <int DEG>
 __global__ __launch_bounds__(256) void sh_fwd_kernel(int64_t n, int K, const float* __restrict__ dirs,
                                                      const float* __restrict__ coeffs,
                                                      const uint8_t* __restrict__ masks,
                                                      float* __restrict__ out) {
+  // each lane streams its own row: the read side is already at what a pure-read stream reaches on this part
+  // (3.7 TB/s here; a torch reduction over the same bytes 3.8), and with fewer bands in use than K a lane only
+  // touches the lines it needs -- the cooperative LDS route (measured) gains nothing at degree 3 and loses below it
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float o[3] = {0.f, 0.f, 0.f};
@@ -28,22 +40,35 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(int64_t n, int K, const flo
                                                      const float* __restrict__ v_out,
                                                      float* __restrict__ v_coeffs,
                                                      float* __restrict__ v_dirs) {
+  using TL = ShTile<DEG>;
   constexpr int NB = (DEG + 1) * (DEG + 1);
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  __shared__ float s_t[4 * TL::FLOATS];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool live = i < n;
   float acc[NB * 3];
 #pragma unroll
   for (int k = 0; k < NB * 3; ++k) acc[k] = 0.f;
   float vx = 0.f, vy = 0.f, vz = 0.f;
-  if (masks == nullptr || masks[i]) {
+  if (live && (masks == nullptr || masks[i])) {
     const float v[3] = {v_out[3 * i], v_out[3 * i + 1], v_out[3 * i + 2]};
     sh_eval_vjp<DEG, DIRGRAD>(coeffs + i * K * 3, dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], v, acc, vx,
                               vy, vz);
   }
-  float* vc = v_coeffs + i * K * 3;
+  // v_coeffs is dense (masked-out rows are zeros): always the cooperative store
+  float* t = s_t + wave * TL::FLOATS;
+  const int64_t row_w = i - lane;
+#pragma unroll 1
+  for (int h = 0; h < 64 / TL::ROWS; ++h) {
+    if (lane / TL::ROWS == h) {
 #pragma unroll
-  for (int k = 0; k < NB * 3; ++k) vc[k] = acc[k];
-  for (int k = NB * 3; k < K * 3; ++k) vc[k] = 0.f;
+      for (int k = 0; k < NB * 3; ++k) t[(lane % TL::ROWS) * (TL::NB3 + 1) + k] = acc[k];
+    }
+    const int64_t row0 = row_w + h * TL::ROWS;
+    const int rows = (int)min((int64_t)TL::ROWS, n - row0);
+    wave_rows_store<TL::NB3>(t, v_coeffs + row0 * K * 3, rows, K * 3, lane);
+  }
+  if (!live) return;
   if constexpr (DIRGRAD) {
     v_dirs[3 * i] = vx;
     v_dirs[3 * i + 1] = vy;

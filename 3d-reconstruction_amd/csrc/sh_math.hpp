@@ -216,4 +216,33 @@ __device__ __forceinline__ void sh_eval_vjp(const float* __restrict__ coeffs, fl
   }
 }
 
+// ---- wave-cooperative row transfer ---------------------------------------------------------------------------------
+// A lane that stores its own row of K3 = 3K floats (192 B at K = 16) at a K3-float stride makes every store
+// instruction of the wave touch 64 different lines.  Instead the wave writes `rows` CONSECUTIVE rows as one contiguous
+// block of rows * K3 floats, 256 B per instruction, out of a wave-private LDS tile t[rows][NB3 + 1] (odd stride: the
+// per-lane row writes that fill it are bank-conflict free).  Only the first NB3 floats of a row live in the tile
+// (the bands in use); the remaining K3 - NB3 floats of every row are stored as zeros.
+// LDS operations of one wave complete in order, so a wavefront fence is all the synchronisation needed.
+template <int NB3>
+__device__ __forceinline__ void wave_rows_store(const float* __restrict__ t, float* __restrict__ base, int rows, int K3,
+                                                int lane) {
+  constexpr int TS = NB3 + 1;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int total = rows * K3;
+  if (K3 == NB3) {
+    for (int m = lane; m < total; m += 64) base[m] = t[m + m / NB3];
+  } else {
+    const float inv_k3 = 1.f / (float)K3;
+    for (int m = lane; m < total; m += 64) {
+      int g = (int)(((float)m + 0.5f) * inv_k3);
+      int k = m - g * K3;
+      if (k < 0) { --g; k += K3; } else if (k >= K3) { ++g; k -= K3; }
+      base[m] = (k < NB3) ? t[g * TS + k] : 0.f;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 }  // namespace gs
