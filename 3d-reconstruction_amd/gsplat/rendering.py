@@ -5,11 +5,13 @@ radius_clip=4.0).  Same signature, argument meaning, return tuple, `meta` keys a
 errors as gsplat 1.x; the arithmetic runs in hand-written HIP kernels behind the
 C ABI of include/gsplat_mi355x.h -- there is no PyTorch/CPU fallback.
 
-Pipeline (two autograd nodes, five kernels + an integer sort):
+Pipeline (two autograd nodes):
   _ProjectSplats   : gs_projection_fwd  -- projection + SH colours + opacity*compensation + depth
                                           channel + tile boxes/counts, one 64-B splat record per (c, n)
-  _RasterizeSplats : gs_exclusive_scan_i32 -> gs_isect_emit -> gs_radix_sort_pairs_u64_u32
-                     -> gs_isect_offset_encode -> gs_rasterize_fwd (ED normalisation fused)
+  _RasterizeSplats : binned intersection (gs_isect_bin_count -> _offsets -> gs_raster_tile_order -> _scatter ->
+                     gs_isect_tile_sort_front) -> gs_rasterize_fwd (ED normalisation fused) -> redo pass for tiles
+                     whose pixels outlived the sorted front; the emit + radix-sort route beyond 16384 tiles per camera
+On top: the eval re-render cache (EVAL_CACHE), lazy `meta` entries (_Meta), the >4-channel loop, `covars=`.
 """
 from __future__ import annotations
 
