@@ -63,6 +63,8 @@ _SIGNATURES = {
     "gs_raster_tile_order": (ctypes.c_int, [c_int32, _P, c_int64, _P, _P, _P, _P]),
     "gs_densify_accumulate": (ctypes.c_int, [c_int32, c_int32, _P, _P, c_int64, c_float, c_float, c_float, c_int32,
                                              _P, _P, _P, _P]),
+    "gs_activate_fwd": (ctypes.c_int, [c_int64, c_int32, c_int32] + [_P] * 7 + [c_int32] + [_P] * 9),
+    "gs_activate_bwd": (ctypes.c_int, [c_int64, c_int32, c_int32] + [_P] * 6 + [c_int32] + [_P] * 12),
     "gs_mark_visible": (ctypes.c_int, [c_int64, _P, _P, _P]),
     "gs_compact_visible": (ctypes.c_int, [c_int32, c_int32] + [_P] * 10 + [_P]),
 }

@@ -283,6 +283,35 @@ int gs_densify_accumulate(int32_t C, int32_t N, const int32_t* radii /* [C,N] */
                           float* grad_norm_sum /* [N] in/out */, float* vis_counts /* [N] in/out */,
                           float* max_2dsize /* [N] in/out */, void* stream);
 
+/* ---- caller pre-pass, fused (next to the path: SURVEY.md 8(f) rank 1, training half) --------------- */
+/* One kernel per Gaussian class for what VanillaGaussians.get_gaussians (R/models/gaussians/vanilla.py:359-393) and
+ * BasicTrainer.collect_gaussians' torch.cat (R/models/trainers/base.py:365-366) do with ~25 torch ops:
+ *   rgbs = clamp(SH_degree(normalize(means - cam_center), cat(features_dc, features_rest)) + 0.5, 0, 1)
+ *          (degree = -1: rgbs = sigmoid(features_dc), vanilla.py:371-372)
+ *   opacities = sigmoid(raw_opacities) [* opacity_mask, R/models/nodes/rigid.py:493]
+ *   scales = exp(raw_scales)  (scale_mode 0: [n,3]; 1: [n,1] repeated 3x; 2: [n,3], third axis 0; vanilla.py:112-128)
+ *   quats = raw_quats / |raw_quats|,  means copied
+ * written into this class's row slice of the scene-level arrays (the out_* pointers are already offset).
+ * clamp_mask [n] u8 keeps which colour channels passed the clamp (for the backward); finite_flag is one u32 that
+ * gets bit 2*key (NaN) / 2*key+1 (Inf) OR-ed in for key 0 _means, 1 _opacities, 2 _rgbs, 3 _scales, 4 _quats
+ * (the reference's isnan/isinf checks, vanilla.py:388-393, without their ten host synchronisations).
+ * K_rest = rows of features_rest per Gaussian (K - 1); (degree + 1)^2 - 1 <= K_rest. */
+int gs_activate_fwd(int64_t n, int32_t K_rest, int32_t degree, const float* means /* [n,3] */,
+                    const float* cam_center /* [3] device */, const float* features_dc /* [n,3] */,
+                    const float* features_rest /* [n,K_rest,3] */, const float* raw_opacities /* [n] */,
+                    const float* opacity_mask /* [n] or NULL */, const float* raw_scales, int32_t scale_mode,
+                    const float* raw_quats /* [n,4] */, float* out_means, float* out_opacities, float* out_rgbs,
+                    float* out_scales, float* out_quats, uint8_t* clamp_mask, uint32_t* finite_flag, void* stream);
+/* vjp of gs_activate_fwd: gradients of the raw Parameters from the gradients of the class's slices.  The means pass
+ * through (view directions are detached, vanilla.py:366), so v_means needs no kernel.  g_features_rest is written
+ * whole (zeros above the degree in use). */
+int gs_activate_bwd(int64_t n, int32_t K_rest, int32_t degree, const float* means, const float* cam_center,
+                    const float* features_dc, const float* raw_opacities, const float* opacity_mask,
+                    const float* raw_scales, int32_t scale_mode, const float* raw_quats, const uint8_t* clamp_mask,
+                    const float* v_opacities, const float* v_rgbs, const float* v_scales, const float* v_quats,
+                    float* g_features_dc, float* g_features_rest, float* g_raw_opacities, float* g_raw_scales,
+                    float* g_raw_quats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
