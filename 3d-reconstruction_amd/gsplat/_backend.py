@@ -65,6 +65,10 @@ _SIGNATURES = {
                                              _P, _P, _P, _P]),
     "gs_activate_fwd": (ctypes.c_int, [c_int64, c_int32, c_int32] + [_P] * 7 + [c_int32] + [_P] * 9),
     "gs_activate_bwd": (ctypes.c_int, [c_int64, c_int32, c_int32] + [_P] * 6 + [c_int32] + [_P] * 12),
+    "gs_refine_decide": (ctypes.c_int, [c_int64, c_int32, c_int32, c_int32] + [c_float] * 6 + [_P] * 8),
+    "gs_refine_plan": (ctypes.c_int, [c_int64, c_int32, _P, _P, _P, _P, _P, _P]),
+    "gs_refine_gather_rows": (ctypes.c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
+    "gs_refine_split_means": (ctypes.c_int, [c_int64, c_int32] + [_P] * 9),
     "gs_mark_visible": (ctypes.c_int, [c_int64, _P, _P, _P]),
     "gs_compact_visible": (ctypes.c_int, [c_int32, c_int32] + [_P] * 10 + [_P]),
 }

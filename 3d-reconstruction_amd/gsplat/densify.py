@@ -51,3 +51,108 @@ def accumulate_stats(meta: Dict, state: DensifyState, absgrad: bool = True, batc
                                               B.ptr(state.xys_grad_norm), B.ptr(state.vis_counts),
                                               B.ptr(state.max_2Dsize), B.stream_handle(dev)), "gs_densify_accumulate")
     return state
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# split / duplicate / cull of one class and its Adam moments (vanilla.py:197-283, basics.py:162-206)
+
+_PARAM_KEYS = ("means", "features_dc", "features_rest", "opacities", "scales", "quats")
+SCALE_3D, SCALE_BALL, SCALE_2D = 0, 1, 2
+
+
+@dataclass
+class RefineConfig:
+    """The `ctrl_cfg` values `refinement_after` reads, with its step conditions already evaluated by the caller:
+    pass None for a test the reference skips at this step."""
+    densify_grad_thresh: float = 0.0002
+    densify_size_thresh: float = 0.01
+    scene_scale: float = 1.0
+    n_split_samples: int = 2
+    split_screen_size: Optional[float] = None   # None when step >= stop_screen_size_at (vanilla.py:217)
+    cull_alpha_thresh: float = 0.005
+    cull_scale_thresh: Optional[float] = None   # None when step <= reset_alpha_interval (vanilla.py:292)
+    cull_screen_size: Optional[float] = None    # None when step >= stop_screen_size_at (vanilla.py:299)
+    do_densify: bool = True                     # vanilla.py:204-207
+    do_cull: bool = True                        # vanilla.py:262
+    ball_gaussians: bool = False
+    gaussian_2d: bool = False
+
+
+def refine_gaussians(params: Dict[str, Tensor], state: Optional[DensifyState], cfg: RefineConfig,
+                     adam: Optional[Dict[str, Dict[str, Tensor]]] = None, generator: Optional[torch.Generator] = None):
+    """Split + duplicate + cull of one class in one composed pass (see csrc/refine.hip).
+
+    params: the six raw tensors `means [n,3]`, `features_dc [n,3]`, `features_rest [n,K-1,3]`, `opacities [n,1]`,
+    `scales [n,3]` (`[n,1]` for ball Gaussians), `quats [n,4]`; state: this class's accumulators (needed when
+    cfg.do_densify or a screen-size test is on); adam: optional `{key: {"exp_avg": t, "exp_avg_sq": t}}` moments.
+    Returns (new_params, new_adam, info) with rows in the reference's order (survivors, split children sample-major,
+    duplicates; culled rows dropped); new rows get zero moments.  The `randn` draw for the split samples has the
+    reference's shape `(n_split_samples * n_splits, 3)` (vanilla.py:321), so a shared seed gives the same children.
+    One host synchronisation."""
+    from .cuda._wrapper import exclusive_scan_i32
+
+    p = {k: params[k] for k in _PARAM_KEYS}
+    n = p["means"].shape[0]
+    dev = B.require_gpu(*p.values())
+    smode = SCALE_BALL if cfg.ball_gaussians else (SCALE_2D if cfg.gaussian_2d else SCALE_3D)
+    assert p["scales"].shape == ((n, 1) if smode == SCALE_BALL else (n, 3)), p["scales"].shape
+    assert p["opacities"].numel() == n and p["quats"].shape == (n, 4)
+    c = {k: B.f32c(v.detach()) for k, v in p.items()}
+    need_stats = cfg.do_densify or (cfg.do_cull and cfg.cull_scale_thresh is not None and cfg.cull_screen_size is not None)
+    gn = vc = m2 = None
+    if need_stats:
+        assert state is not None and state.xys_grad_norm is not None and state.vis_counts is not None \
+            and state.max_2Dsize is not None, "densification statistics missing (vanilla.py:210)"
+        gn, vc, m2 = (B.f32c(t).reshape(-1) for t in (state.xys_grad_norm, state.vis_counts, state.max_2Dsize))
+        assert gn.numel() == n and vc.numel() == n and m2.numel() == n
+    neg = lambda v, scale=1.0: -1.0 if v is None else float(v) * scale
+    flags = torch.empty(n, device=dev, dtype=torch.uint8)
+    counts = torch.empty(4 * n + 1, device=dev, dtype=torch.int32)
+    L, stream = B.lib(), B.stream_handle(dev)
+    with torch.cuda.device(dev):
+        B.check(L.gs_refine_decide(n, smode, int(cfg.do_densify), int(cfg.do_cull), cfg.densify_grad_thresh,
+                                   cfg.densify_size_thresh * cfg.scene_scale, neg(cfg.split_screen_size),
+                                   cfg.cull_alpha_thresh, neg(cfg.cull_scale_thresh, cfg.scene_scale),
+                                   neg(cfg.cull_screen_size), B.ptr(c["scales"]), B.ptr(c["opacities"]), B.ptr(gn),
+                                   B.ptr(vc), B.ptr(m2), B.ptr(flags), B.ptr(counts), stream), "gs_refine_decide")
+    scan, _ = exclusive_scan_i32(counts)
+    idx = torch.tensor([0, n, 2 * n, 3 * n, 4 * n], device=dev)
+    b = scan[idx].tolist()  # the one host synchronisation
+    n_splits, n_self, n_ksplit, n_kdup = b[1] - b[0], b[2] - b[1], b[3] - b[2], b[4] - b[3]
+    ns = int(cfg.n_split_samples)
+    n_out = n_self + ns * n_ksplit + n_kdup
+    samples = torch.randn((ns * n_splits, 3), device=dev, generator=generator)
+    src = torch.empty(n_out, device=dev, dtype=torch.int32)
+    kinds = torch.empty(n_out, device=dev, dtype=torch.uint8)
+    sidx = torch.empty(n_out, device=dev, dtype=torch.int32)
+    new_p: Dict[str, Tensor] = {}
+    new_adam: Optional[Dict[str, Dict[str, Tensor]]] = {} if adam is not None else None
+
+    def gather(t: Tensor, mode: int) -> Tensor:
+        t = B.f32c(t.detach())
+        W = 1
+        for d in t.shape[1:]:
+            W *= int(d)
+        out = torch.empty((n_out,) + tuple(t.shape[1:]), device=dev, dtype=torch.float32)
+        B.check(L.gs_refine_gather_rows(n_out, W, mode, B.ptr(src), B.ptr(kinds), B.ptr(flags), B.ptr(t), B.ptr(out),
+                                        stream), "gs_refine_gather_rows")
+        return out
+
+    with torch.cuda.device(dev):
+        if n_out > 0:  # (everything culled: the outputs are empty and there is nothing to plan)
+            B.check(L.gs_refine_plan(n, ns, B.ptr(flags), B.ptr(scan), B.ptr(src), B.ptr(kinds), B.ptr(sidx), stream),
+                    "gs_refine_plan")
+        new_means = torch.empty(n_out, 3, device=dev, dtype=torch.float32)
+        B.check(L.gs_refine_split_means(n_out, smode, B.ptr(src), B.ptr(kinds), B.ptr(sidx), B.ptr(c["means"]),
+                                        B.ptr(c["scales"]), B.ptr(c["quats"]), B.ptr(samples), B.ptr(new_means),
+                                        stream), "gs_refine_split_means")
+        new_p["means"] = new_means
+        for k in _PARAM_KEYS[1:]:
+            new_p[k] = gather(c[k], 2 if k == "scales" else 0)
+        if adam is not None:
+            for k, st in adam.items():
+                new_adam[k] = {m: gather(v, 1) for m, v in st.items() if torch.is_tensor(v) and v.dim() > 0
+                               and v.shape[0] == n}
+    info = {"n_before": n, "n_after": n_out, "n_splits": n_splits, "n_kept_split_children": ns * n_ksplit,
+            "n_kept_dups": n_kdup, "n_culled_old": n - n_self}
+    return new_p, new_adam, info

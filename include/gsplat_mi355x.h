@@ -312,6 +312,35 @@ int gs_activate_bwd(int64_t n, int32_t K_rest, int32_t degree, const float* mean
                     float* g_features_dc, float* g_features_rest, float* g_raw_opacities, float* g_raw_scales,
                     float* g_raw_quats, void* stream);
 
+/* ---- densify / cull of one Gaussian class (next to the path: SURVEY.md 8(f) rank 2, second half) ---- */
+/* VanillaGaussians.refinement_after (R/models/gaussians/vanilla.py:197-283: split_gaussians :314-342, dup_gaussians
+ * :344-357, cull_gaussians :285-312) and the Adam-moment surgery (R/models/gaussians/basics.py:162-206), composed:
+ * decide -> gs_exclusive_scan_i32 over counts [4n+1] -> plan -> one gather per tensor.
+ * gs_refine_decide: flags [n] u8 (1 split, 2 dup, 4 row survives, 8 its split children survive, 16 its duplicate
+ * survives); counts [4n+1] i32 = the columns {split, survives, children survive, duplicate survives} then a 0.
+ * densify_size_thresh / cull_scale_thresh are already multiplied by scene_scale; split_screen_size, cull_scale_thresh,
+ * cull_screen_size < 0 switch that test off (the reference's step conditions :217, :292, :299). */
+int gs_refine_decide(int64_t n, int32_t scale_mode, int32_t do_densify, int32_t do_cull, float densify_grad_thresh,
+                     float densify_size_thresh, float split_screen_size, float cull_alpha_thresh,
+                     float cull_scale_thresh, float cull_screen_size, const float* raw_scales,
+                     const float* raw_opacities, const float* grad_norm_sum, const float* vis_counts,
+                     const float* max_2dsize, uint8_t* flags, int32_t* counts, void* stream);
+/* scan = exclusive scan of counts.  Output rows in the reference's order [survivors | split children, sample-major |
+ * duplicates]: n_out = scan[4n] - scan[n] + (n_split_samples - 1) * (scan[3n] - scan[2n]).  kinds: 0 old row,
+ * 1 duplicate, 2 + s split child of sample s; sample_idx = s * n_splits + rank among ALL split rows (the row of the
+ * reference's `randn((samps * n_splits, 3))` draw, :321), -1 otherwise. */
+int gs_refine_plan(int64_t n, int32_t n_split_samples, const uint8_t* flags, const int32_t* scan, int32_t* src_rows,
+                   uint8_t* kinds, int32_t* sample_idx, void* stream);
+/* out [n_out,W] = in [src_rows,:]; mode 0 copy (features, opacities, quats), 1 zeros for new rows (Adam exp_avg /
+ * exp_avg_sq), 2 log(exp(x) / 1.6) on rows whose source was split (scales, :338-339).  W <= 256. */
+int gs_refine_gather_rows(int64_t n_out, int32_t W, int32_t mode, const int32_t* src_rows, const uint8_t* kinds,
+                          const uint8_t* flags, const float* in, float* out, void* stream);
+/* new means: split children = mean + R(q/|q|) (exp(scales) * samples[sample_idx]) (:321-329), other rows copied. */
+int gs_refine_split_means(int64_t n_out, int32_t scale_mode, const int32_t* src_rows, const uint8_t* kinds,
+                          const int32_t* sample_idx, const float* means, const float* raw_scales,
+                          const float* raw_quats, const float* samples /* [n_split_samples * n_splits, 3] */,
+                          float* out_means, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
