@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--height", type=int, default=375)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=4)
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="multi-rank dry run on fewer GPUs than ranks: gloo backend, device = LOCAL_RANK %% device_count "
+                         "(exercises the N > 1 code path on a one-GPU box; the number it prints is not a result)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,10 +121,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    if args.rehearse_gloo:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1 and args.gpus == 1, (world, args.gpus)
 
     from gsplat import _backend as B
@@ -140,6 +148,10 @@ def main():
     wc_flat, wa_flat = wc.reshape(-1), wa.reshape(-1)
     plist = list(params.values())
 
+    def note(msg):
+        if args.rehearse_gloo:
+            print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True)
+
     def step():
         for p in plist:
             p.grad = None
@@ -151,11 +163,14 @@ def main():
         loss = torch.dot(rc.reshape(-1), wc_flat) + torch.dot(ra.reshape(-1), wa_flat)
         loss.backward()
         if world > 1:
+            note("backward done, all-reduce")
             all_reduce_gradients(plist)
         return meta
 
+    note("first step")
     for _ in range(args.warmup):
         meta = step()
+        note("warm-up step done")
     if args.warmup == 0:
         meta = step()
     V = int((meta["radii"] > 0).sum().item())
@@ -210,7 +225,9 @@ def main():
             "config": {"workload": "configs[1]: 1M Gaussians, SH deg 3, 5 cams 1242x375 batched fwd+bwd, RGB+ED, "
                                    "absgrad + antialiased, packed=False", "gaussians": N, "cams_per_gpu": C,
                        "width": W, "height": H, "visible_pairs_V": V, "n_isects_I": I,
-                       "parallelism": f"camera/frame DP x{world}, grad all-reduce (RCCL)" if world > 1 else "single GPU"},
+                       "parallelism": (f"camera/frame DP x{world}, grad all-reduce "
+                                       f"({'gloo REHEARSAL, not a result' if args.rehearse_gloo else 'RCCL'})")
+                       if world > 1 else "single GPU"},
             "roofline": roofline,
             "step_hbm_floor": {"algorithmic_bytes_per_step": total_bytes,
                                "frac_of_hbm_peak": round(total_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
