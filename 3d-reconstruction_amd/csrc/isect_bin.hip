@@ -20,15 +20,16 @@
 
 namespace gs {
 
-constexpr int BIN_THREADS = 256;
+constexpr int BIN_THREADS = 1024;      // 16 waves: a quarter as many slices as with 256 threads, so the scatter's
+                                       // (slice, tile) runs are 4x longer (0.129 -> 0.106 ms at config 2)
 constexpr int BIN_COOP = 16;            // tile boxes larger than this are walked by the whole wave
 constexpr int BIN_MAX_TILES = 16384;    // per camera: LDS histogram of 64 KiB
 
 // ------------------------------------------------------------------------------------------ count / scatter
-// A workgroup streams its row slice 256 rows at a time.  Most rows of a camera are culled (tiles_per_gauss == 0),
+// A workgroup streams its row slice 1024 rows at a time.  Most rows of a camera are culled (tiles_per_gauss == 0),
 // so the visible ones are first compacted into an LDS queue {row id, tile box, depth bits} and the tile walk then
 // runs on full waves.  cnt[] is the camera's tile histogram (count) or the per-tile write cursor (scatter).
-constexpr int BIN_QCAP = 1024;
+constexpr int BIN_QCAP = 2 * BIN_THREADS;
 
 template <bool SCATTER>
 __device__ __forceinline__ void bin_drain(uint32_t* cnt, const uint4* q, int qn, int tile_w, uint2* __restrict__ pairs) {
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(BIN_THREADS) void isect_bin_kernel(int32_t N, int32
           make_uint4((uint32_t)idx, (uint32_t)__float_as_int(r3.y), (uint32_t)__float_as_int(r3.z), dbits);
     }
     cntg = cnt_next;
-    // a block appends at most 256 entries, so draining every QCAP/256 blocks (a data-independent, workgroup-uniform
+    // a block appends at most BIN_THREADS entries, so draining every QCAP/256 blocks (a data-independent, workgroup-uniform
     // decision) can never overflow the queue
     const int it = (nb - n0) / BIN_THREADS;
     if ((it % (BIN_QCAP / BIN_THREADS)) == (BIN_QCAP / BIN_THREADS) - 1 || nb + BIN_THREADS >= n1) {
@@ -122,17 +123,39 @@ __global__ __launch_bounds__(BIN_THREADS) void isect_bin_kernel(int32_t N, int32
   }
 }
 
-// per tile: exclusive prefix over the slices (in place), total -> counts
+// per tile: exclusive prefix over the slices (in place), total -> counts.  A workgroup owns 64 consecutive tiles; its
+// four waves split the slices (sum their quarter, exchange the quarter totals through LDS, then write the prefixes), so
+// the serial chain per tile is n_slices / 4 long and there are 4x the waves to hide it (one wave per 64 tiles left
+// most CUs empty: 0.056 -> see DESIGN.md at 9600 tiles x 512 slices).
 __global__ __launch_bounds__(256) void bin_slice_prefix_kernel(int32_t C, int32_t T, int32_t n_slices,
                                                                uint32_t* __restrict__ table,
                                                                int32_t* __restrict__ counts) {
-  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= (int64_t)C * T) return;
-  const int c = (int)(g / T), t = (int)(g - (int64_t)c * T);
+  __shared__ uint32_t part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t g = (int64_t)blockIdx.x * 64 + lane;
+  const bool live = g < (int64_t)C * T;
+  const int c = live ? (int)(g / T) : 0, t = live ? (int)(g - (int64_t)c * T) : 0;
   uint32_t* col = table + (int64_t)c * n_slices * T + t;
+  const int per = (n_slices + 3) / 4;
+  const int s0 = min(n_slices, w * per), s1 = min(n_slices, s0 + per);
+  uint32_t sum = 0;
+  if (live) {
+    int s = s0;
+    for (; s + 4 <= s1; s += 4) {
+      const uint32_t v0 = col[(int64_t)(s + 0) * T], v1 = col[(int64_t)(s + 1) * T];
+      const uint32_t v2 = col[(int64_t)(s + 2) * T], v3 = col[(int64_t)(s + 3) * T];
+      sum += (v0 + v1) + (v2 + v3);
+    }
+    for (; s < s1; ++s) sum += col[(int64_t)s * T];
+  }
+  part[w][lane] = sum;
+  __syncthreads();
+  if (!live) return;
   uint32_t run = 0;
-  int s = 0;
-  for (; s + 4 <= n_slices; s += 4) {
+  for (int k = 0; k < w; ++k) run += part[k][lane];
+  if (w == 3) counts[g] = (int32_t)(run + sum);
+  int s = s0;
+  for (; s + 4 <= s1; s += 4) {
     const uint32_t v0 = col[(int64_t)(s + 0) * T], v1 = col[(int64_t)(s + 1) * T];
     const uint32_t v2 = col[(int64_t)(s + 2) * T], v3 = col[(int64_t)(s + 3) * T];
     col[(int64_t)(s + 0) * T] = run; run += v0;
@@ -140,12 +163,11 @@ __global__ __launch_bounds__(256) void bin_slice_prefix_kernel(int32_t C, int32_
     col[(int64_t)(s + 2) * T] = run; run += v2;
     col[(int64_t)(s + 3) * T] = run; run += v3;
   }
-  for (; s < n_slices; ++s) {
+  for (; s < s1; ++s) {
     const uint32_t v = col[(int64_t)s * T];
     col[(int64_t)s * T] = run;
     run += v;
   }
-  counts[g] = (int32_t)run;
 }
 
 // single workgroup: exclusive scan of the per-tile totals -> offsets, grand total -> *total
@@ -733,7 +755,7 @@ extern "C" int gs_isect_bin_offsets(int32_t C, int32_t tile_w, int32_t tile_h, i
   const int T = tile_w * tile_h;
   const int64_t n_tiles = (int64_t)C * T;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gs::bin_slice_prefix_kernel, dim3((unsigned)gs::ceil_div(n_tiles, 256)), dim3(256), 0, s, C, T,
+  hipLaunchKernelGGL(gs::bin_slice_prefix_kernel, dim3((unsigned)gs::ceil_div(n_tiles, 64)), dim3(256), 0, s, C, T,
                      n_slices, table, tile_counts);
   hipLaunchKernelGGL(gs::bin_offsets_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_counts, isect_offsets, total);
   GS_CHECK_LAUNCH();

@@ -324,7 +324,8 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
     C, N = tiles_per_gauss.shape
     T = tile_width * tile_height
     lib, st = B.lib(), B.stream_handle(dev)
-    n_slices = max(1, min(512, max(1024 // C, 1), -(-max(N, 1) // 2048)))
+    # 1024-thread workgroups, two per CU over all cameras (fewer, longer slices keep the scatter's runs long)
+    n_slices = max(1, min(max(512 // C, 1), -(-max(N, 1) // 4096)))
     table = torch.empty(C * n_slices * T, device=dev, dtype=torch.int32)
     counts = torch.empty(C * T, device=dev, dtype=torch.int32)
     offsets = torch.empty(C, tile_height, tile_width, device=dev, dtype=torch.int32)

@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
     (2, 20_000, 13, 7, 6000, 5),        # 5 distinct depths: every front has a crowded bucket -> deferred, sorted whole
     (1, 3_000, 5, 4, 1500, 1 << 20),
     (3, 500, 78, 24, 0, 3),             # nothing longer than 1024: the short classes only
+    (1, 9_000, 128, 128, 0, 1 << 20),   # 16384 tiles per camera: the largest LDS histogram the binned route takes
 ])
 def test_front_prefix_matches_full_order(gpu_device, C, N, TW, TH, hot, levels):
     from gsplat.cuda._wrapper import FRONT_K_TARGET, isect_tiles_binned
