@@ -75,7 +75,9 @@ __global__ __launch_bounds__(BIN_THREADS) void isect_bin_kernel(int32_t N, int32
                                                                 const int32_t* __restrict__ tiles_per_gauss,
                                                                 uint32_t* __restrict__ table,
                                                                 const int32_t* __restrict__ offsets,
-                                                                uint2* __restrict__ pairs) {
+                                                                uint2* __restrict__ pairs,
+                                                                uint4* __restrict__ vis_list,
+                                                                int32_t* __restrict__ vis_cnt) {
   extern __shared__ uint32_t cnt[];  // [T]
   __shared__ uint4 q[BIN_QCAP];
   __shared__ int q_n;
@@ -88,6 +90,10 @@ __global__ __launch_bounds__(BIN_THREADS) void isect_bin_kernel(int32_t N, int32
   __syncthreads();
   const int n0 = slice * rows_per_slice;
   const int n1 = min(N, n0 + rows_per_slice);
+  // count pass only: the slice's queue entries also go to its segment of vis_list, which the region scatter reads
+  const bool keep = !SCATTER && vis_list != nullptr;
+  uint4* seg = keep ? vis_list + ((int64_t)c * n_slices + slice) * rows_per_slice : nullptr;
+  int written = 0;
   int cntg = (n0 + tid < n1) ? tiles_per_gauss[(int64_t)c * N + n0 + tid] : 0;
   for (int nb = n0; nb < n1; nb += BIN_THREADS) {
     const int64_t idx = (int64_t)c * N + nb + tid;
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(BIN_THREADS) void isect_bin_kernel(int32_t N, int32
     qbase = __shfl(qbase, 0);
     if (vis) {
       const float4 r3 = reinterpret_cast<const float4*>(splats + idx * REC)[3];
-      const uint32_t dbits = SCATTER ? (uint32_t)__float_as_int(splats[idx * REC + 10]) : 0u;
+      const uint32_t dbits = (SCATTER || keep) ? (uint32_t)__float_as_int(splats[idx * REC + 10]) : 0u;
       q[qbase + __popcll(vm & lt_mask)] =
           make_uint4((uint32_t)idx, (uint32_t)__float_as_int(r3.y), (uint32_t)__float_as_int(r3.z), dbits);
     }
@@ -111,7 +117,12 @@ __global__ __launch_bounds__(BIN_THREADS) void isect_bin_kernel(int32_t N, int32
     const int it = (nb - n0) / BIN_THREADS;
     if ((it % (BIN_QCAP / BIN_THREADS)) == (BIN_QCAP / BIN_THREADS) - 1 || nb + BIN_THREADS >= n1) {
       __syncthreads();
-      bin_drain<SCATTER>(cnt, q, q_n, tile_w, pairs);
+      const int qn = q_n;
+      if (keep) {
+        for (int e = tid; e < qn; e += BIN_THREADS) seg[written + e] = q[e];
+        written += qn;
+      }
+      bin_drain<SCATTER>(cnt, q, qn, tile_w, pairs);
       __syncthreads();
       if (tid == 0) q_n = 0;
       __syncthreads();
@@ -120,6 +131,69 @@ __global__ __launch_bounds__(BIN_THREADS) void isect_bin_kernel(int32_t N, int32
   if (!SCATTER) {
     __syncthreads();
     for (int t = tid; t < T; t += BIN_THREADS) trow[t] = cnt[t];
+    if (keep && tid == 0) vis_cnt[c * n_slices + slice] = written;
+  }
+}
+
+// Scatter by tile REGION.  isect_bin_kernel<true> gives a workgroup one row slice and all of the camera's tiles, so the
+// run it writes into one tile segment is (hits of the slice) / T entries long -- 8 at config 2, 2 at 9600 tiles: 8-B
+// stores spread over as many partially written lines as there are tiles, most of which leave L2 before they fill.
+// Here a workgroup owns a band of tile rows (1 / R of the tiles) and a GROUP of G consecutive slices, walks the group's
+// visible lists (written by the count pass: 16 B per visible row, contiguous) clipped to its band, and so writes runs
+// G * R times as long from a cursor table R times smaller.  Which slot a hit gets inside its tile segment differs from
+// the slice scatter's; the per-tile sort that follows fixes the order completely either way.
+__global__ __launch_bounds__(BIN_THREADS) void isect_region_scatter_kernel(
+    int32_t tile_w, int32_t tile_h, int32_t T, int32_t n_slices, int32_t G, int32_t R, int32_t seg_cap,
+    const uint4* __restrict__ vis_list, const int32_t* __restrict__ vis_cnt, const uint32_t* __restrict__ table,
+    const int32_t* __restrict__ offsets, uint2* __restrict__ pairs) {
+  extern __shared__ uint32_t cur[];  // [band tiles]
+  const int c = blockIdx.y, g = blockIdx.x / R, r = blockIdx.x - g * R;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int ty0 = (int)((int64_t)r * tile_h / R), ty1 = (int)((int64_t)(r + 1) * tile_h / R);
+  const int t0 = ty0 * tile_w, nt = (ty1 - ty0) * tile_w;
+  if (nt == 0) return;
+  const int s0 = g * G, s1 = min(n_slices, s0 + G);
+  // table holds the exclusive prefix over slices: the group's first slice marks where the group's hits start
+  const uint32_t* trow = table + ((int64_t)c * n_slices + s0) * T + t0;
+  const int32_t* orow = offsets + (int64_t)c * T + t0;
+  for (int t = tid; t < nt; t += BIN_THREADS) cur[t] = (uint32_t)orow[t] + trow[t];
+  __syncthreads();
+  for (int s = s0; s < s1; ++s) {
+    const int n = vis_cnt[c * n_slices + s];
+    const uint4* seg = vis_list + ((int64_t)c * n_slices + s) * seg_cap;
+    for (int e0 = (tid >> 6) * 64; e0 < n; e0 += BIN_THREADS) {
+      const int e = e0 + lane;
+      int cntg = 0, x0 = 0, y0 = 0, x1 = 0;
+      uint32_t idx = 0, dbits = 0;
+      if (e < n) {
+        const uint4 en = seg[e];
+        idx = en.x; dbits = en.w;
+        x0 = en.y & 0xffff; x1 = en.z & 0xffff;
+        y0 = max((int)(en.y >> 16), ty0);
+        cntg = max(0, min((int)(en.z >> 16), ty1) - y0) * (x1 - x0);
+      }
+      if (cntg > 0 && cntg <= BIN_COOP) {
+        int tj = x0, trow0 = (y0 - ty0) * tile_w;
+        for (int t = 0; t < cntg; ++t) {
+          const uint32_t pos = atomicAdd(&cur[trow0 + tj], 1u);
+          pairs[pos] = make_uint2(dbits, idx);
+          if (++tj == x1) { tj = x0; trow0 += tile_w; }
+        }
+      }
+      unsigned long long big = __ballot(cntg > BIN_COOP);
+      while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const int b_cnt = __shfl(cntg, src), b_x0 = __shfl(x0, src), b_y0 = __shfl(y0, src) - ty0;
+        const int b_w = __shfl(x1, src) - b_x0;
+        const uint32_t b_d = __shfl(dbits, src), b_idx = __shfl(idx, src);
+        for (int t = lane; t < b_cnt; t += 64) {
+          const int ti = b_y0 + t / b_w, tj = b_x0 + t % b_w;
+          const uint32_t pos = atomicAdd(&cur[ti * tile_w + tj], 1u);
+          pairs[pos] = make_uint2(b_d, b_idx);
+        }
+      }
+    }
   }
 }
 
@@ -733,17 +807,27 @@ static int bin_check(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, int32
 
 extern "C" int32_t gs_isect_bin_max_tiles(void) { return gs::BIN_MAX_TILES; }
 
+static int bin_slice_rows(int32_t N, int32_t n_slices) {
+  int rows = (int)gs::ceil_div(N > 0 ? N : 1, n_slices);
+  return (int)gs::ceil_div(rows, gs::BIN_THREADS) * gs::BIN_THREADS;
+}
+
+extern "C" int32_t gs_isect_bin_slice_rows(int32_t N, int32_t n_slices) {
+  return n_slices < 1 ? 0 : bin_slice_rows(N, n_slices);
+}
+
 extern "C" int gs_isect_bin_count(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, const float* splats,
-                                  const int32_t* tiles_per_gauss, int32_t n_slices, uint32_t* table, void* stream) {
+                                  const int32_t* tiles_per_gauss, int32_t n_slices, uint32_t* table,
+                                  uint64_t* vis_list, int32_t* vis_counts, void* stream) {
   int st = bin_check(C, N, tile_w, tile_h, n_slices);
   if (st != GS_OK) return st;
   if (!table || (N > 0 && (!splats || !tiles_per_gauss))) return GS_ERR_INVALID_ARG;
+  if ((vis_list == nullptr) != (vis_counts == nullptr) || ((uintptr_t)vis_list & 15)) return GS_ERR_INVALID_ARG;
   const int T = tile_w * tile_h;
-  int rows = (int)gs::ceil_div(N > 0 ? N : 1, n_slices);
-  rows = (int)gs::ceil_div(rows, gs::BIN_THREADS) * gs::BIN_THREADS;
   hipLaunchKernelGGL((gs::isect_bin_kernel<false>), dim3((unsigned)n_slices, (unsigned)C), dim3(gs::BIN_THREADS),
-                     (size_t)T * sizeof(uint32_t), (hipStream_t)stream, N, tile_w, T, n_slices, rows, splats,
-                     tiles_per_gauss, table, (const int32_t*)nullptr, (uint2*)nullptr);
+                     (size_t)T * sizeof(uint32_t), (hipStream_t)stream, N, tile_w, T, n_slices,
+                     bin_slice_rows(N, n_slices), splats, tiles_per_gauss, table, (const int32_t*)nullptr,
+                     (uint2*)nullptr, reinterpret_cast<uint4*>(vis_list), vis_counts);
   GS_CHECK_LAUNCH();
   return GS_OK;
 }
@@ -770,11 +854,33 @@ extern "C" int gs_isect_bin_scatter(int32_t C, int32_t N, int32_t tile_w, int32_
   if (N == 0) return GS_OK;
   if (!splats || !tiles_per_gauss || !table || !isect_offsets || !pairs) return GS_ERR_INVALID_ARG;
   const int T = tile_w * tile_h;
-  int rows = (int)gs::ceil_div(N > 0 ? N : 1, n_slices);
-  rows = (int)gs::ceil_div(rows, gs::BIN_THREADS) * gs::BIN_THREADS;
   hipLaunchKernelGGL((gs::isect_bin_kernel<true>), dim3((unsigned)n_slices, (unsigned)C), dim3(gs::BIN_THREADS),
-                     (size_t)T * sizeof(uint32_t), (hipStream_t)stream, N, tile_w, T, n_slices, rows, splats,
-                     tiles_per_gauss, const_cast<uint32_t*>(table), isect_offsets, reinterpret_cast<uint2*>(pairs));
+                     (size_t)T * sizeof(uint32_t), (hipStream_t)stream, N, tile_w, T, n_slices,
+                     bin_slice_rows(N, n_slices), splats, tiles_per_gauss, const_cast<uint32_t*>(table), isect_offsets,
+                     reinterpret_cast<uint2*>(pairs), (uint4*)nullptr, (int32_t*)nullptr);
+  GS_CHECK_LAUNCH();
+  return GS_OK;
+}
+
+extern "C" int gs_isect_bin_scatter_regions(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, int32_t n_slices,
+                                            int32_t slices_per_group, int32_t n_regions, const uint64_t* vis_list,
+                                            const int32_t* vis_counts, const uint32_t* table,
+                                            const int32_t* isect_offsets, uint64_t* pairs, void* stream) {
+  int st = bin_check(C, N, tile_w, tile_h, n_slices);
+  if (st != GS_OK) return st;
+  if (slices_per_group < 1 || n_regions < 1 || n_regions > 65535) return GS_ERR_INVALID_ARG;
+  if (N == 0) return GS_OK;
+  if (!vis_list || !vis_counts || !table || !isect_offsets || !pairs || ((uintptr_t)vis_list & 15))
+    return GS_ERR_INVALID_ARG;
+  const int T = tile_w * tile_h;
+  const int groups = (int)gs::ceil_div(n_slices, slices_per_group);
+  if ((int64_t)groups * n_regions > 0x7fffffff) return GS_ERR_UNSUPPORTED;
+  const int band_rows = (int)gs::ceil_div(tile_h, n_regions) + 1;
+  hipLaunchKernelGGL(gs::isect_region_scatter_kernel, dim3((unsigned)(groups * n_regions), (unsigned)C),
+                     dim3(gs::BIN_THREADS), (size_t)band_rows * tile_w * sizeof(uint32_t), (hipStream_t)stream, tile_w,
+                     tile_h, T, n_slices, slices_per_group, n_regions, bin_slice_rows(N, n_slices),
+                     reinterpret_cast<const uint4*>(vis_list), vis_counts, table, isect_offsets,
+                     reinterpret_cast<uint2*>(pairs));
   GS_CHECK_LAUNCH();
   return GS_OK;
 }

@@ -312,6 +312,9 @@ class FrontSort:
         self.pairs = None  # (stream-ordered: the allocator reuses it only behind the sort)
 
 
+REGION_SCATTER = True  # scatter from the count pass's visible lists by tile band (False: by row slice, from the records)
+
+
 def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int, tile_height: int,
                        front: bool = False):
     """isect_tiles + sort + isect_offset_encode in one binned pipeline (include/gsplat_mi355x.h, "binned isect_tiles").
@@ -330,9 +333,18 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
     counts = torch.empty(C * T, device=dev, dtype=torch.int32)
     offsets = torch.empty(C, tile_height, tile_width, device=dev, dtype=torch.int32)
     total = torch.empty(1, device=dev, dtype=torch.int64)
+    # region scatter: two bands of tile rows x groups of slices, about one 1024-thread workgroup per CU (measured best
+    # of 1..32 bands x 1..32 slices per group at 5 x 1242x375 and 1 x 1920x1280: DESIGN.md section 6)
+    regions = 2 if tile_height >= 2 else 1
+    group = max(1, -(-(n_slices * C * regions) // 256))
+    vis_list = vis_cnt = None
+    if REGION_SCATTER:
+        seg = int(lib.gs_isect_bin_slice_rows(N, n_slices))
+        vis_list = torch.empty(C * n_slices * seg, 2, device=dev, dtype=torch.int64)
+        vis_cnt = torch.empty(C * n_slices, device=dev, dtype=torch.int32)
     with torch.cuda.device(dev), B.timed("gs_isect_bin_count", dev):
         B.check(lib.gs_isect_bin_count(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss), n_slices,
-                                       B.ptr(table), st), "gs_isect_bin_count")
+                                       B.ptr(table), B.ptr(vis_list), B.ptr(vis_cnt), st), "gs_isect_bin_count")
     with torch.cuda.device(dev), B.timed("gs_isect_bin_offsets", dev):
         B.check(lib.gs_isect_bin_offsets(C, tile_width, tile_height, n_slices, B.ptr(table), B.ptr(counts),
                                          B.ptr(offsets), B.ptr(total), st), "gs_isect_bin_offsets")
@@ -350,8 +362,14 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
         return isect_ids, flatten_ids, offsets, None, None
     pairs = torch.empty(n_isects, device=dev, dtype=torch.int64)
     with torch.cuda.device(dev), B.timed("gs_isect_bin_scatter", dev):
-        B.check(lib.gs_isect_bin_scatter(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss), n_slices,
-                                         B.ptr(table), B.ptr(offsets), B.ptr(pairs), st), "gs_isect_bin_scatter")
+        if vis_list is not None:
+            B.check(lib.gs_isect_bin_scatter_regions(C, N, tile_width, tile_height, n_slices, group, regions,
+                                                     B.ptr(vis_list), B.ptr(vis_cnt), B.ptr(table), B.ptr(offsets),
+                                                     B.ptr(pairs), st), "gs_isect_bin_scatter_regions")
+        else:
+            B.check(lib.gs_isect_bin_scatter(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
+                                             n_slices, B.ptr(table), B.ptr(offsets), B.ptr(pairs), st),
+                    "gs_isect_bin_scatter")
     if front and order is not None:
         # `counts` (the list lengths) becomes sorted_counts: the front kernel overwrites the long tiles' entries
         with torch.cuda.device(dev), B.timed("gs_isect_tile_sort", dev):

@@ -179,13 +179,25 @@ int gs_isect_offset_encode(int64_t n_isects, const int64_t* isect_ids_sorted,
  *   total        int64  device scalar                 n_isects
  *   pairs        uint64 [n_isects]                    scratch (low word depth bits, high word flat row id)      */
 int32_t gs_isect_bin_max_tiles(void);
+/* vis_list / vis_counts (both or neither): the count pass also leaves every slice's visible rows as 16-byte entries
+ * {flat row id, tile box lo, tile box hi, depth bits} in vis_list [C][n_slices][gs_isect_bin_slice_rows(N, n_slices)]
+ * (uint64 pairs, 16-byte aligned) and their number in vis_counts [C][n_slices], for gs_isect_bin_scatter_regions. */
+int32_t gs_isect_bin_slice_rows(int32_t N, int32_t n_slices);
 int gs_isect_bin_count(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, const float* splats,
-                       const int32_t* tiles_per_gauss, int32_t n_slices, uint32_t* table, void* stream);
+                       const int32_t* tiles_per_gauss, int32_t n_slices, uint32_t* table, uint64_t* vis_list,
+                       int32_t* vis_counts, void* stream);
 int gs_isect_bin_offsets(int32_t C, int32_t tile_w, int32_t tile_h, int32_t n_slices, uint32_t* table,
                          int32_t* tile_counts, int32_t* isect_offsets, int64_t* total, void* stream);
 int gs_isect_bin_scatter(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, const float* splats,
                          const int32_t* tiles_per_gauss, int32_t n_slices, const uint32_t* table,
                          const int32_t* isect_offsets, uint64_t* pairs, void* stream);
+/* Same result as gs_isect_bin_scatter up to the order inside a tile segment (which the sort fixes), from the visible
+ * lists of the count pass: a workgroup owns a band of tile rows (n_regions bands) and slices_per_group consecutive
+ * slices, so the runs it writes into a tile segment are slices_per_group * n_regions times as long. */
+int gs_isect_bin_scatter_regions(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, int32_t n_slices,
+                                 int32_t slices_per_group, int32_t n_regions, const uint64_t* vis_list,
+                                 const int32_t* vis_counts, const uint32_t* table, const int32_t* isect_offsets,
+                                 uint64_t* pairs, void* stream);
 int gs_isect_tile_sort(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets, int64_t n_isects,
                        const int32_t* tile_order /* launch order from gs_raster_tile_order, or NULL */,
                        const int32_t* size_classes /* its size_classes output (device int32[3]), or NULL */,

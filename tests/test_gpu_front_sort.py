@@ -52,6 +52,14 @@ def test_front_prefix_matches_full_order(gpu_device, C, N, TW, TH, hot, levels):
         assert np.array_equal(kg[off[t]:end[t]], keys[off[t]:end[t]]) and np.array_equal(fg[off[t]:end[t]], ids[off[t]:end[t]])
     fs.finalize()
     assert np.array_equal(k.cpu().numpy(), keys) and np.array_equal(f.cpu().numpy(), ids)
+    # the slice scatter (no visible lists) fills the segments in another order; the sorted result is the same
+    import gsplat.cuda._wrapper as W
+    W.REGION_SCATTER = False
+    try:
+        k2, f2, o2, _, _ = isect_tiles_binned(rec, tiles, TW, TH, front=False)
+    finally:
+        W.REGION_SCATTER = True
+    assert torch.equal(k2, k) and torch.equal(f2, f) and torch.equal(o2, o)
 
 
 def _dense_scene(n, opac_lo, opac_hi, seed=3):
