@@ -8,7 +8,7 @@ C ABI of include/gsplat_mi355x.h -- there is no PyTorch/CPU fallback.
 Pipeline (two autograd nodes):
   _ProjectSplats   : gs_projection_fwd  -- projection + SH colours + opacity*compensation + depth
                                           channel + tile boxes/counts, one 64-B splat record per (c, n)
-  _RasterizeSplats : binned intersection (gs_isect_bin_count -> _offsets -> gs_raster_tile_order -> _scatter ->
+  _RasterizeSplats : binned intersection (gs_isect_bin_count -> _offsets -> gs_raster_tile_order -> _scatter_regions ->
                      gs_isect_tile_sort_front) -> gs_rasterize_fwd (ED normalisation fused) -> redo pass for tiles
                      whose pixels outlived the sorted front; the emit + radix-sort route beyond 16384 tiles per camera
 On top: the eval re-render cache (EVAL_CACHE), lazy `meta` entries (_Meta), the >4-channel loop, `covars=`.
