@@ -1,0 +1,236 @@
+// RGB loss terms next to the rasterizer's output, fused.
+// The reference computes, on the [H,W,3] render and ground truth (both first multiplied by a [H,W] validity mask),
+//   Ll1     = |gt - pred|.mean()                                   (models/trainers/base.py:540)
+//   simloss = 1 - SSIM(data_range=1, size_average=True, channel=3)(gt, pred)          (base.py:114, :541)
+// with pytorch_msssim 1.0.0 (requirements.txt:7; not in /root/reference, restated from its published algorithm): an
+// 11-tap Gaussian window (sigma 1.5, normalised), separable VALID convolutions (no padding: the SSIM map is
+// (H-10) x (W-10)), per pixel and channel
+//   m = (2 mu1 mu2 + C1)(2 s12 + C2) / ((mu1^2 + mu2^2 + C1)(s1 + s2 + C2)),  C1 = 0.01^2, C2 = 0.03^2,
+// and the mean of m over pixels and channels.  In torch that is ten depthwise convolutions and ~25 elementwise passes
+// forward, twice that backward.  Here: one forward kernel (tile in LDS, horizontal then vertical filter of the five
+// moments x, y, x^2, y^2, xy, the SSIM value, the three partial derivatives the backward needs, the L1 term, per-block
+// partial sums), a one-block deterministic reduction, and one backward kernel (transposed filter of the derivative
+// maps + the L1 sign + the mask).  HBM-bound: forward reads 2 x 12 B + 4 B and writes 36 B per pixel, backward reads
+// 36 + 28 B and writes 12 B.
+#include "gs_common.hpp"
+
+namespace gs {
+
+constexpr int SS_WIN = 11, SS_HALO = SS_WIN - 1;
+constexpr int SS_T = 16;                 // output tile edge
+constexpr int SS_IN = SS_T + SS_HALO;    // 26 input rows / columns per tile
+constexpr float SS_C1 = 0.01f * 0.01f, SS_C2 = 0.03f * 0.03f;
+
+struct SsimWin { float w[SS_WIN]; };
+
+// block (bx, by) owns the pixels [by*16, +16) x [bx*16, +16): their L1 terms, and the SSIM map entries with those
+// indices (map entry (oy, ox) covers input rows oy..oy+10, columns ox..ox+10; valid for oy < H-10, ox < W-10)
+__global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(int H, int W, SsimWin win, const float* __restrict__ pred,
+                                                          const float* __restrict__ gt, const float* __restrict__ mask,
+                                                          float* __restrict__ maps, float* __restrict__ partials) {
+  __shared__ float sx[SS_IN][SS_IN * 3 + 1], sy[SS_IN][SS_IN * 3 + 1];
+  __shared__ float hb[5][SS_IN][SS_T * 3 + 1];
+  __shared__ float red[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int y0 = blockIdx.y * SS_T, x0 = blockIdx.x * SS_T;
+  const int Ho = H - SS_HALO, Wo = W - SS_HALO;
+  float l1 = 0.f;
+  // load the 26 x 26 x 3 tile of both images (masked), zero outside the image
+  for (int i = tid; i < SS_IN * SS_IN; i += 256) {
+    const int r = i / SS_IN, c = i - r * SS_IN;
+    const int y = y0 + r, x = x0 + c;
+    float p[3] = {0.f, 0.f, 0.f}, g[3] = {0.f, 0.f, 0.f};
+    if (y < H && x < W) {
+      const int64_t o = ((int64_t)y * W + x) * 3;
+      const float mk = mask ? mask[(int64_t)y * W + x] : 1.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { p[k] = pred[o + k] * mk; g[k] = gt[o + k] * mk; }
+      if (r < SS_T && c < SS_T) l1 += fabsf(g[0] - p[0]) + fabsf(g[1] - p[1]) + fabsf(g[2] - p[2]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { sx[r][c * 3 + k] = p[k]; sy[r][c * 3 + k] = g[k]; }
+  }
+  __syncthreads();
+  // horizontal filter of the five moments: 26 rows x 16 columns x 3 channels
+  for (int i = tid; i < SS_IN * SS_T * 3; i += 256) {
+    const int r = i / (SS_T * 3), j = i - r * (SS_T * 3);  // j = column * 3 + channel
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+    for (int t = 0; t < SS_WIN; ++t) {
+      const float x = sx[r][j + 3 * t], y = sy[r][j + 3 * t], w = win.w[t];
+      a0 = fmaf(w, x, a0); a1 = fmaf(w, y, a1);
+      a2 = fmaf(w, x * x, a2); a3 = fmaf(w, y * y, a3); a4 = fmaf(w, x * y, a4);
+    }
+    hb[0][r][j] = a0; hb[1][r][j] = a1; hb[2][r][j] = a2; hb[3][r][j] = a3; hb[4][r][j] = a4;
+  }
+  __syncthreads();
+  // vertical filter + SSIM: one thread per output pixel, three channels
+  float ss = 0.f;
+  {
+    const int r = tid >> 4, c = tid & 15;
+    const int oy = y0 + r, ox = x0 + c;
+    if (oy < Ho && ox < Wo) {
+      float dm[9];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+        for (int t = 0; t < SS_WIN; ++t) {
+          const float w = win.w[t];
+          mu1 = fmaf(w, hb[0][r + t][c * 3 + k], mu1);
+          mu2 = fmaf(w, hb[1][r + t][c * 3 + k], mu2);
+          e11 = fmaf(w, hb[2][r + t][c * 3 + k], e11);
+          e22 = fmaf(w, hb[3][r + t][c * 3 + k], e22);
+          e12 = fmaf(w, hb[4][r + t][c * 3 + k], e12);
+        }
+        const float s1 = e11 - mu1 * mu1, s2 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+        const float A = mu1 * mu1 + mu2 * mu2 + SS_C1, Bq = s1 + s2 + SS_C2;
+        const float Cq = 2.f * mu1 * mu2 + SS_C1, D = 2.f * s12 + SS_C2;
+        const float iA = 1.f / A, iB = 1.f / Bq;
+        const float m = Cq * D * iA * iB;
+        ss += m;
+        // partial derivatives w.r.t. the PRED-side moments (mu1 with E[x^2], E[xy] held fixed; s1; s12)
+        dm[k] = 2.f * iA * iB * (mu2 * (D - Cq) - mu1 * Cq * D * iA + mu1 * Cq * D * iB);
+        dm[3 + k] = -m * iB;
+        dm[6 + k] = 2.f * Cq * iA * iB;
+      }
+      if (maps) {
+        float* o = maps + ((int64_t)oy * Wo + ox) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o[k] = dm[k];
+      }
+    }
+  }
+  // block partial sums (fixed order: deterministic)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { l1 += __shfl_down(l1, off); ss += __shfl_down(ss, off); }
+  if (lane == 0) { red[0][wave] = l1; red[1][wave] = ss; }
+  __syncthreads();
+  if (tid == 0) {
+    const int64_t b = (int64_t)blockIdx.y * gridDim.x + blockIdx.x, nb = (int64_t)gridDim.x * gridDim.y;
+    partials[b] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    partials[nb + b] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
+// out[0] = sum(partials[0..nb)) * s0, out[1] = sum(partials[nb..2nb)) * s1; one workgroup, fixed summation order
+__global__ __launch_bounds__(1024) void l1_ssim_reduce_kernel(int64_t nb, const float* __restrict__ partials, double s0,
+                                                              double s1, float* __restrict__ out) {
+  __shared__ double red[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double a = 0.0, b = 0.0;
+  for (int64_t i = tid; i < nb; i += 1024) { a += (double)partials[i]; b += (double)partials[nb + i]; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+  if (lane == 0) { red[0][wave] = a; red[1][wave] = b; }
+  __syncthreads();
+  if (tid == 0) {
+    double ta = 0.0, tb = 0.0;
+    for (int w = 0; w < 16; ++w) { ta += red[0][w]; tb += red[1][w]; }
+    out[0] = (float)(ta * s0);
+    out[1] = (float)(tb * s1);
+  }
+}
+
+// v_pred[p] = mask[p] * ( g_l1 * sign(pred_m - gt_m) / (3HW)
+//                         + g_ssim / (3 Ho Wo) * sum_{o in window of p} w(o,p) (dmu1[o] + 2 x[p] ds1[o] + y[p] ds12[o]) )
+__global__ __launch_bounds__(256) void l1_ssim_bwd_kernel(int H, int W, SsimWin win, const float* __restrict__ pred,
+                                                          const float* __restrict__ gt, const float* __restrict__ mask,
+                                                          const float* __restrict__ maps, const float* __restrict__ g_out,
+                                                          float s_l1, float s_ssim, float* __restrict__ v_pred) {
+  // map tile: entries (oy, ox) with oy in [y0-10, y0+16), ox in [x0-10, x0+16): 26 x 26 x 9 floats
+  __shared__ float sm[SS_IN][SS_IN * 9 + 1];
+  __shared__ float hb[SS_IN][SS_T * 9 + 1];
+  const int tid = threadIdx.x;
+  const int y0 = blockIdx.y * SS_T, x0 = blockIdx.x * SS_T;
+  const int Ho = H - SS_HALO, Wo = W - SS_HALO;
+  for (int i = tid; i < SS_IN * SS_IN * 9; i += 256) {
+    const int r = i / (SS_IN * 9), j = i - r * (SS_IN * 9);
+    const int c = j / 9, k = j - c * 9;
+    const int oy = y0 - SS_HALO + r, ox = x0 - SS_HALO + c;
+    sm[r][j] = (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) ? maps[((int64_t)oy * Wo + ox) * 9 + k] : 0.f;
+  }
+  __syncthreads();
+  // horizontal: input column x receives from map columns ox = x - t (t = 0..10) with weight w[t]
+  for (int i = tid; i < SS_IN * SS_T * 9; i += 256) {
+    const int r = i / (SS_T * 9), j = i - r * (SS_T * 9);
+    const int c = j / 9, k = j - c * 9;
+    float a = 0.f;
+#pragma unroll
+    for (int t = 0; t < SS_WIN; ++t) a = fmaf(win.w[t], sm[r][(c + SS_HALO - t) * 9 + k], a);
+    hb[r][j] = a;
+  }
+  __syncthreads();
+  const int r = tid >> 4, c = tid & 15;
+  const int y = y0 + r, x = x0 + c;
+  if (y >= H || x >= W) return;
+  const float mk = mask ? mask[(int64_t)y * W + x] : 1.f;
+  const float gl1 = g_out[0] * s_l1, gss = g_out[1] * s_ssim;
+  const int64_t o = ((int64_t)y * W + x) * 3;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < SS_WIN; ++t) {
+      const float w = win.w[t];
+      d0 = fmaf(w, hb[r + SS_HALO - t][c * 9 + k], d0);
+      d1 = fmaf(w, hb[r + SS_HALO - t][c * 9 + 3 + k], d1);
+      d2 = fmaf(w, hb[r + SS_HALO - t][c * 9 + 6 + k], d2);
+    }
+    const float p = pred[o + k] * mk, g = gt[o + k] * mk;
+    const float diff = p - g;
+    const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);  // torch.abs has gradient 0 at 0
+    v_pred[o + k] = mk * (gl1 * sgn + gss * (d0 + 2.f * p * d1 + g * d2));
+  }
+}
+
+static SsimWin make_window() {
+  SsimWin w;
+  // pytorch_msssim builds the window in fp32: exp(-(i - 5)^2 / (2 * 1.5^2)), then a division by the fp32 sum
+  float gf[SS_WIN], sf = 0.f;
+  for (int i = 0; i < SS_WIN; ++i) {
+    const double c = (double)(i - SS_WIN / 2);
+    gf[i] = (float)exp(-(c * c) / (2.0 * 1.5 * 1.5));
+    sf += gf[i];
+  }
+  for (int i = 0; i < SS_WIN; ++i) w.w[i] = gf[i] / sf;
+  return w;
+}
+
+}  // namespace gs
+
+extern "C" int64_t gs_l1_ssim_workspace_floats(int32_t H, int32_t W) {
+  if (H < 1 || W < 1) return 0;
+  return 2 * gs::ceil_div((int64_t)H, gs::SS_T) * gs::ceil_div((int64_t)W, gs::SS_T);
+}
+
+// out[0] = mean |gt*mask - pred*mask| over H*W*3, out[1] = SSIM(gt*mask, pred*mask) (mean of the (H-10)x(W-10)x3 map).
+// maps (NULL when no gradient is needed): [(H-10)*(W-10)*9] floats kept for gs_l1_ssim_bwd.
+extern "C" int gs_l1_ssim_fwd(int32_t H, int32_t W, const float* pred, const float* gt, const float* mask, float* maps,
+                              float* workspace, int64_t workspace_floats, float* out, void* stream) {
+  if (H <= gs::SS_HALO || W <= gs::SS_HALO) return GS_ERR_UNSUPPORTED;  // pytorch_msssim skips the filter there
+  if (!pred || !gt || !workspace || !out) return GS_ERR_INVALID_ARG;
+  if (workspace_floats < gs_l1_ssim_workspace_floats(H, W)) return GS_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)gs::ceil_div(W, gs::SS_T), (unsigned)gs::ceil_div(H, gs::SS_T));
+  const int64_t nb = (int64_t)grid.x * grid.y;
+  hipLaunchKernelGGL(gs::l1_ssim_fwd_kernel, grid, dim3(256), 0, s, H, W, gs::make_window(), pred, gt, mask, maps,
+                     workspace);
+  hipLaunchKernelGGL(gs::l1_ssim_reduce_kernel, dim3(1), dim3(1024), 0, s, nb, workspace,
+                     1.0 / ((double)H * W * 3.0), 1.0 / ((double)(H - gs::SS_HALO) * (W - gs::SS_HALO) * 3.0), out);
+  GS_CHECK_LAUNCH();
+  return GS_OK;
+}
+
+// v_pred [H,W,3] = g_out[0] * dL1/dpred + g_out[1] * dSSIM/dpred (g_out: 2 floats on the device).
+extern "C" int gs_l1_ssim_bwd(int32_t H, int32_t W, const float* pred, const float* gt, const float* mask,
+                              const float* maps, const float* g_out, float* v_pred, void* stream) {
+  if (H <= gs::SS_HALO || W <= gs::SS_HALO) return GS_ERR_UNSUPPORTED;
+  if (!pred || !gt || !maps || !g_out || !v_pred) return GS_ERR_INVALID_ARG;
+  const dim3 grid((unsigned)gs::ceil_div(W, gs::SS_T), (unsigned)gs::ceil_div(H, gs::SS_T));
+  hipLaunchKernelGGL(gs::l1_ssim_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, H, W, gs::make_window(), pred,
+                     gt, mask, maps, g_out, (float)(1.0 / ((double)H * W * 3.0)),
+                     (float)(1.0 / ((double)(H - gs::SS_HALO) * (W - gs::SS_HALO) * 3.0)), v_pred);
+  GS_CHECK_LAUNCH();
+  return GS_OK;
+}

@@ -71,6 +71,9 @@ _SIGNATURES = {
     "gs_refine_plan": (ctypes.c_int, [c_int64, c_int32, _P, _P, _P, _P, _P, _P]),
     "gs_refine_gather_rows": (ctypes.c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
     "gs_refine_split_means": (ctypes.c_int, [c_int64, c_int32] + [_P] * 9),
+    "gs_l1_ssim_workspace_floats": (c_int64, [c_int32, c_int32]),
+    "gs_l1_ssim_fwd": (ctypes.c_int, [c_int32, c_int32, _P, _P, _P, _P, _P, c_int64, _P, _P]),
+    "gs_l1_ssim_bwd": (ctypes.c_int, [c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "gs_mark_visible": (ctypes.c_int, [c_int64, _P, _P, _P]),
     "gs_compact_visible": (ctypes.c_int, [c_int32, c_int32] + [_P] * 10 + [_P]),
 }

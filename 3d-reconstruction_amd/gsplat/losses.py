@@ -1,0 +1,62 @@
+"""RGB loss terms on the rasterizer's output in two kernels.
+
+`l1_ssim(pred, gt, mask)` returns what `BasicTrainer.compute_losses` computes at
+/root/reference/3D-Reconstruction-main/models/trainers/base.py:533-541 with torch ops and
+`pytorch_msssim.SSIM(data_range=1.0, size_average=True, channel=3)` (base.py:114): the mean absolute difference and the
+SSIM of the masked images, differentiable w.r.t. `pred`:
+
+    Ll1, ssim = l1_ssim(outputs["rgb"], image_infos["pixels"], valid_loss_mask)
+    loss = w_rgb * Ll1 + w_ssim * (1 - ssim)
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _backend as B
+
+
+class _L1Ssim(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt, mask, need):
+        dev = B.require_gpu(pred, gt, mask)
+        H, W = pred.shape[0], pred.shape[1]
+        pred_c, gt_c = B.f32c(pred), B.f32c(gt)
+        mask_c = B.f32c(mask) if mask is not None else None
+        L = B.lib()
+        nws = int(L.gs_l1_ssim_workspace_floats(H, W))
+        ws = torch.empty(nws, device=dev, dtype=torch.float32)
+        maps = torch.empty((H - 10) * (W - 10) * 9, device=dev, dtype=torch.float32) if need else None
+        out = torch.empty(2, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev), B.timed("gs_l1_ssim_fwd", dev):
+            B.check(L.gs_l1_ssim_fwd(H, W, B.ptr(pred_c), B.ptr(gt_c), B.ptr(mask_c), B.ptr(maps), B.ptr(ws), nws,
+                                     B.ptr(out), B.stream_handle(dev)), "gs_l1_ssim_fwd")
+        ctx.has_mask = mask is not None
+        if need:
+            ctx.save_for_backward(pred_c, gt_c, mask_c if mask_c is not None else out, maps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        pred, gt, mask, maps = ctx.saved_tensors
+        mask = mask if ctx.has_mask else None
+        dev = pred.device
+        H, W = pred.shape[0], pred.shape[1]
+        g = B.f32c(g_out)
+        v = torch.empty_like(pred)
+        with torch.cuda.device(dev), B.timed("gs_l1_ssim_bwd", dev):
+            B.check(B.lib().gs_l1_ssim_bwd(H, W, B.ptr(pred), B.ptr(gt), B.ptr(mask), B.ptr(maps), B.ptr(g), B.ptr(v),
+                                           B.stream_handle(dev)), "gs_l1_ssim_bwd")
+        return v, None, None, None
+
+
+def l1_ssim(pred: Tensor, gt: Tensor, mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """pred, gt: [H,W,3] in [0,1]; mask: [H,W] (multiplied into both images, base.py:533-534) or None.
+    Returns (Ll1, ssim) as 0-d tensors; `1 - ssim` is the reference's `simloss`.  H, W must exceed 10."""
+    assert pred.dim() == 3 and pred.shape[-1] == 3 and gt.shape == pred.shape, (pred.shape, gt.shape)
+    assert mask is None or tuple(mask.shape) == tuple(pred.shape[:2]), "mask must be [H,W]"
+    assert pred.shape[0] > 10 and pred.shape[1] > 10, "images must be larger than the 11-tap window"
+    out = _L1Ssim.apply(pred, gt, mask, bool(pred.requires_grad and torch.is_grad_enabled()))
+    return out[0], out[1]

@@ -353,6 +353,21 @@ int gs_refine_split_means(int64_t n_out, int32_t scale_mode, const int32_t* src_
                           const float* raw_quats, const float* samples /* [n_split_samples * n_splits, 3] */,
                           float* out_means, void* stream);
 
+/* ---- RGB loss terms on the render (next to the path: SURVEY.md 8(f) rank 4) ------------------------- */
+/* BasicTrainer.compute_losses' rgb terms (R/models/trainers/base.py:533-541): with pred, gt [H,W,3] and an optional
+ * validity mask [H,W] multiplied into both,
+ *   out[0] = |gt - pred|.mean()                                           (:540)
+ *   out[1] = pytorch_msssim.SSIM(data_range=1, size_average=True, channel=3)(gt, pred)   (:114, :541; the caller takes 1 - )
+ * (11-tap sigma-1.5 Gaussian window, VALID separable filter, K = (0.01, 0.03); pytorch_msssim 1.0.0,
+ * R/requirements.txt:7).  H, W > 10.  maps: NULL, or [(H-10)*(W-10)*9] floats kept for the backward.
+ * workspace: gs_l1_ssim_workspace_floats(H, W) floats (per-workgroup partial sums; the reduction order is fixed). */
+int64_t gs_l1_ssim_workspace_floats(int32_t H, int32_t W);
+int gs_l1_ssim_fwd(int32_t H, int32_t W, const float* pred, const float* gt, const float* mask, float* maps,
+                   float* workspace, int64_t workspace_floats, float* out /* [2] */, void* stream);
+/* v_pred [H,W,3] = g_out[0] * d out[0] / d pred + g_out[1] * d out[1] / d pred; g_out: 2 floats on the device. */
+int gs_l1_ssim_bwd(int32_t H, int32_t W, const float* pred, const float* gt, const float* mask, const float* maps,
+                   const float* g_out, float* v_pred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
