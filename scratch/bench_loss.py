@@ -38,21 +38,26 @@ def t(fn, iters=20):
     return (time.perf_counter() - t0) / iters * 1e3
 
 
-for H, W in ((375, 1242), (1280, 1920)):
-    gt = torch.rand(H, W, 3, device=dev)
-    mask = (torch.rand(H, W, device=dev) > 0.1).float()
-    pred = torch.rand(H, W, 3, device=dev, requires_grad=True)
+def main():
+    for H, W in ((375, 1242), (1280, 1920)):
+        gt = torch.rand(H, W, 3, device=dev)
+        mask = (torch.rand(H, W, device=dev) > 0.1).float()
+        pred = torch.rand(H, W, 3, device=dev, requires_grad=True)
 
-    def ref():
-        pred.grad = None
-        l1, s = torch_chain(pred, gt, mask)
-        (0.8 * l1 + 0.2 * (1 - s)).backward()
+        def ref():
+            pred.grad = None
+            l1, s = torch_chain(pred, gt, mask)
+            (0.8 * l1 + 0.2 * (1 - s)).backward()
 
-    def fused():
-        pred.grad = None
-        l1, s = l1_ssim(pred, gt, mask)
-        (0.8 * l1 + 0.2 * (1 - s)).backward()
+        def fused():
+            pred.grad = None
+            l1, s = l1_ssim(pred, gt, mask)
+            (0.8 * l1 + 0.2 * (1 - s)).backward()
 
-    print(f"{H}x{W}: torch chain {t(ref):.3f} ms   fused {t(fused):.3f} ms (fwd + bwd)")
-    from gsplat import _backend as B
-    B.profiling_start(); fused(); fused(); print({k: round(v[1], 4) for k, v in B.profiling_stop().items()})
+        print(f"{H}x{W}: torch chain {t(ref):.3f} ms   fused {t(fused):.3f} ms (fwd + bwd)")
+        from gsplat import _backend as B
+        B.profiling_start(); fused(); fused(); print({k: round(v[1], 4) for k, v in B.profiling_stop().items()})
+
+
+if __name__ == "__main__":
+    main()
