@@ -74,6 +74,8 @@ _SIGNATURES = {
     "gs_l1_ssim_workspace_floats": (c_int64, [c_int32, c_int32]),
     "gs_l1_ssim_fwd": (ctypes.c_int, [c_int32, c_int32, _P, _P, _P, _P, _P, c_int64, _P, _P]),
     "gs_l1_ssim_bwd": (ctypes.c_int, [c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "gs_cube_texture_fwd": (ctypes.c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
+    "gs_cube_texture_bwd": (ctypes.c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
     "gs_mark_visible": (ctypes.c_int, [c_int64, _P, _P, _P]),
     "gs_compact_visible": (ctypes.c_int, [c_int32, c_int32] + [_P] * 10 + [_P]),
 }

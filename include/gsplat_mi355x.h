@@ -368,6 +368,17 @@ int gs_l1_ssim_fwd(int32_t H, int32_t W, const float* pred, const float* gt, con
 int gs_l1_ssim_bwd(int32_t H, int32_t W, const float* pred, const float* gt, const float* mask, const float* maps,
                    const float* g_out, float* v_pred, void* stream);
 
+/* ---- sky environment light (next to the path: SURVEY.md 8(f) rank 4) --------------------------------- */
+/* EnvLight.forward (R/models/modules.py:191-203): nvdiffrast.torch.texture(base[None], l, filter_mode='linear',
+ * boundary_mode='cube') -- bilinear, seamless cube-map lookup (OpenGL face order +x,-x,+y,-y,+z,-z and orientation).
+ * tex [6,R,R,C], dirs [n,3] (any length), rot: NULL or 9 floats on the device, d' = rot d (the `to_opengl` matrix of
+ * modules.py:186,194), out [n,C].  nvdiffrast is CUDA-only and not available here: parity unpinned. */
+int gs_cube_texture_fwd(int64_t n, int32_t R, int32_t C, const float* tex, const float* dirs, const float* rot,
+                        float* out, void* stream);
+/* v_tex [6,R,R,C] (zeroed by the caller) += the transpose of the lookup applied to v_out [n,C]. */
+int gs_cube_texture_bwd(int64_t n, int32_t R, int32_t C, const float* dirs, const float* rot, const float* v_out,
+                        float* v_tex, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
