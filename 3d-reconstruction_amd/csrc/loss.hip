@@ -234,3 +234,154 @@ extern "C" int gs_l1_ssim_bwd(int32_t H, int32_t W, const float* pred, const flo
   GS_CHECK_LAUNCH();
   return GS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The per-pixel scalar terms of compute_losses in their shipped configuration (R/configs/omnire.yaml:24-31):
+//   sky / mask loss   binary_cross_entropy(opacity * valid, (1 - sky_mask) * valid).mean()        (base.py:536-550,
+//                     models/losses.py:86-88; torch clamps both logs at -100)
+//   depth loss        DepthLoss("l1", normalize=False, inverse=False, "mean_on_hit") (losses.py:96-199, base.py:553-557):
+//                     hit = (gt > 0) * valid; mean of |pred*hit - gt*hit| over {gt*hit in (0.01, 80), pred*hit > 1e-4}
+//   opacity entropy   (-p log p).mean(), p = clamp(opacity, 1e-6, 1 - 1e-6)                       (base.py:568-573)
+// One pass over the pixels -> per-workgroup partial sums {bce, depth, depth count, entropy} -> fixed-order reduction.
+// The torch version is ~30 elementwise kernels, a boolean-mask gather (with its host synchronisation) and four
+// reductions.
+namespace gs {
+
+struct PixelTerms { float bce, dabs, dcnt, ent; };
+
+__device__ __forceinline__ PixelTerms pixel_terms(int64_t i, const float* opacity, const float* depth, const float* sky,
+                                                  const float* valid, const float* lidar, float max_depth) {
+  PixelTerms t = {0.f, 0.f, 0.f, 0.f};
+  const float vm = valid ? valid[i] : 1.f, op = opacity[i];
+  if (sky) {
+    const float p = op * vm, g = (1.f - sky[i]) * vm;
+    t.bce = -(g * fmaxf(logf(p), -100.f) + (1.f - g) * fmaxf(logf(1.f - p), -100.f));
+  }
+  if (lidar) {
+    const float gtd = lidar[i], hit = (gtd > 0.f ? 1.f : 0.f) * vm;
+    const float pd = depth[i] * hit, gd = gtd * hit;
+    if (gd > 0.01f && gd < max_depth && pd > 0.0001f) { t.dabs = fabsf(pd - gd); t.dcnt = 1.f; }
+  }
+  const float pc = fminf(fmaxf(op, 1e-6f), 1.f - 1e-6f);
+  t.ent = -pc * logf(pc);
+  return t;
+}
+
+__global__ __launch_bounds__(256) void pixel_losses_fwd_kernel(int64_t n, const float* __restrict__ opacity,
+                                                               const float* __restrict__ depth,
+                                                               const float* __restrict__ sky,
+                                                               const float* __restrict__ valid,
+                                                               const float* __restrict__ lidar, float max_depth,
+                                                               float* __restrict__ partials) {
+  __shared__ float red[4][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
+    const PixelTerms t = pixel_terms(i, opacity, depth, sky, valid, lidar, max_depth);
+    a[0] += t.bce; a[1] += t.dabs; a[2] += t.dcnt; a[3] += t.ent;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a[k] += __shfl_down(a[k], off);
+    if (lane == 0) red[k][wave] = a[k];
+  }
+  __syncthreads();
+  if (tid < 4) partials[(int64_t)tid * gridDim.x + blockIdx.x] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
+}
+
+// out = {bce mean, depth mean over the selected pixels, number of selected pixels, entropy mean}
+__global__ __launch_bounds__(256) void pixel_losses_reduce_kernel(int nb, int64_t n, const float* __restrict__ partials,
+                                                                  float* __restrict__ out) {
+  __shared__ double red[4][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i = tid; i < nb; i += 256)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] += (double)partials[(int64_t)k * nb + i];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a[k] += __shfl_down(a[k], off);
+    if (lane == 0) red[k][wave] = a[k];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double s[4];
+    for (int k = 0; k < 4; ++k) s[k] = (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]);
+    out[0] = (float)(s[0] / (double)n);
+    out[1] = (float)(s[1] / s[2]);  // no selected pixel: 0 / 0 = NaN, as torch's mean of an empty tensor
+    out[2] = (float)s[2];
+    out[3] = (float)(s[3] / (double)n);
+  }
+}
+
+__global__ __launch_bounds__(256) void pixel_losses_bwd_kernel(int64_t n, const float* __restrict__ opacity,
+                                                               const float* __restrict__ depth,
+                                                               const float* __restrict__ sky,
+                                                               const float* __restrict__ valid,
+                                                               const float* __restrict__ lidar, float max_depth,
+                                                               const float* __restrict__ fwd_out,
+                                                               const float* __restrict__ g_out,
+                                                               float* __restrict__ v_opacity, float* __restrict__ v_depth) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float vm = valid ? valid[i] : 1.f, op = opacity[i];
+  const float inv_n = 1.f / (float)n;
+  float vo = 0.f;
+  if (sky) {
+    // torch's binary_cross_entropy backward: (p - g) / max(p (1 - p), 1e-12)
+    const float p = op * vm, g = (1.f - sky[i]) * vm;
+    vo += g_out[0] * inv_n * vm * (p - g) / fmaxf((1.f - p) * p, 1e-12f);
+  }
+  if (op >= 1e-6f && op <= 1.f - 1e-6f) vo += g_out[3] * inv_n * -(logf(op) + 1.f);
+  v_opacity[i] = vo;
+  if (v_depth) {
+    float vd = 0.f;
+    if (lidar) {
+      const float gtd = lidar[i], hit = (gtd > 0.f ? 1.f : 0.f) * vm;
+      const float pd = depth[i] * hit, gd = gtd * hit;
+      if (gd > 0.01f && gd < max_depth && pd > 0.0001f) {
+        const float d = pd - gd;
+        vd = g_out[1] / fwd_out[2] * hit * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+      }
+    }
+    v_depth[i] = vd;
+  }
+}
+
+constexpr int PL_BLOCKS = 1024;
+
+}  // namespace gs
+
+extern "C" int64_t gs_pixel_losses_workspace_floats(void) { return 4 * gs::PL_BLOCKS; }
+
+// out [4] = {sky BCE mean, depth L1 mean over the selected pixels, their count, opacity-entropy mean} over n = H*W pixels.
+// sky_mask / lidar_depth may be NULL (that term is 0 / NaN); depth may be NULL when lidar_depth is.
+extern "C" int gs_pixel_losses_fwd(int64_t n, const float* opacity, const float* depth, const float* sky_mask,
+                                   const float* valid_mask, const float* lidar_depth, float max_depth, float* workspace,
+                                   int64_t workspace_floats, float* out, void* stream) {
+  if (n < 1 || !opacity || !workspace || !out || (lidar_depth && !depth)) return GS_ERR_INVALID_ARG;
+  if (workspace_floats < gs_pixel_losses_workspace_floats()) return GS_ERR_WORKSPACE;
+  const int nb = (int)std::min<int64_t>(gs::PL_BLOCKS, gs::ceil_div(n, 256));
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gs::pixel_losses_fwd_kernel, dim3(nb), dim3(256), 0, s, n, opacity, depth, sky_mask, valid_mask,
+                     lidar_depth, max_depth, workspace);
+  hipLaunchKernelGGL(gs::pixel_losses_reduce_kernel, dim3(1), dim3(256), 0, s, nb, n, workspace, out);
+  GS_CHECK_LAUNCH();
+  return GS_OK;
+}
+
+// v_opacity [n] (and v_depth [n], may be NULL) from g_out [4] (upstream gradients of out; entry 2 is ignored) and the
+// forward's out (for the selected-pixel count).
+extern "C" int gs_pixel_losses_bwd(int64_t n, const float* opacity, const float* depth, const float* sky_mask,
+                                   const float* valid_mask, const float* lidar_depth, float max_depth,
+                                   const float* fwd_out, const float* g_out, float* v_opacity, float* v_depth,
+                                   void* stream) {
+  if (n < 1 || !opacity || !fwd_out || !g_out || !v_opacity || (lidar_depth && !depth)) return GS_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(gs::pixel_losses_bwd_kernel, dim3((unsigned)gs::ceil_div(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, n, opacity, depth, sky_mask, valid_mask, lidar_depth, max_depth, fwd_out,
+                     g_out, v_opacity, v_depth);
+  GS_CHECK_LAUNCH();
+  return GS_OK;
+}

@@ -74,6 +74,9 @@ _SIGNATURES = {
     "gs_l1_ssim_workspace_floats": (c_int64, [c_int32, c_int32]),
     "gs_l1_ssim_fwd": (ctypes.c_int, [c_int32, c_int32, _P, _P, _P, _P, _P, c_int64, _P, _P]),
     "gs_l1_ssim_bwd": (ctypes.c_int, [c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "gs_pixel_losses_workspace_floats": (c_int64, []),
+    "gs_pixel_losses_fwd": (ctypes.c_int, [c_int64, _P, _P, _P, _P, _P, c_float, _P, c_int64, _P, _P]),
+    "gs_pixel_losses_bwd": (ctypes.c_int, [c_int64, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P]),
     "gs_cube_texture_fwd": (ctypes.c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
     "gs_cube_texture_bwd": (ctypes.c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
     "gs_mark_visible": (ctypes.c_int, [c_int64, _P, _P, _P]),

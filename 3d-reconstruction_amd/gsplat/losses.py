@@ -60,3 +60,67 @@ def l1_ssim(pred: Tensor, gt: Tensor, mask: Optional[Tensor] = None) -> Tuple[Te
     assert pred.shape[0] > 10 and pred.shape[1] > 10, "images must be larger than the 11-tap window"
     out = _L1Ssim.apply(pred, gt, mask, bool(pred.requires_grad and torch.is_grad_enabled()))
     return out[0], out[1]
+
+
+class _PixelLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, opacity, depth, sky_mask, valid_mask, lidar_depth, max_depth):
+        dev = B.require_gpu(opacity, depth, sky_mask, valid_mask, lidar_depth)
+        n = opacity.numel()
+        c = [B.f32c(t).reshape(-1) if t is not None else None for t in (opacity, depth, sky_mask, valid_mask, lidar_depth)]
+        L = B.lib()
+        nws = int(L.gs_pixel_losses_workspace_floats())
+        ws = torch.empty(nws, device=dev, dtype=torch.float32)
+        out = torch.empty(4, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev), B.timed("gs_pixel_losses_fwd", dev):
+            B.check(L.gs_pixel_losses_fwd(n, B.ptr(c[0]), B.ptr(c[1]), B.ptr(c[2]), B.ptr(c[3]), B.ptr(c[4]),
+                                          float(max_depth), B.ptr(ws), nws, B.ptr(out), B.stream_handle(dev)),
+                    "gs_pixel_losses_fwd")
+        ctx.present = [t is not None for t in c]
+        ctx.max_depth = float(max_depth)
+        ctx.shapes = (tuple(opacity.shape), tuple(depth.shape) if depth is not None else None)
+        ctx.save_for_backward(out, *[t for t in c if t is not None])
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        out, *rest = ctx.saved_tensors
+        it = iter(rest)
+        c = [next(it) if pr else None for pr in ctx.present]
+        dev = out.device
+        n = c[0].numel()
+        g = B.f32c(g_out)
+        need_depth = c[1] is not None and ctx.needs_input_grad[1]
+        v_op = torch.empty(n, device=dev, dtype=torch.float32)
+        v_dp = torch.empty(n, device=dev, dtype=torch.float32) if need_depth else None
+        with torch.cuda.device(dev), B.timed("gs_pixel_losses_bwd", dev):
+            B.check(B.lib().gs_pixel_losses_bwd(n, B.ptr(c[0]), B.ptr(c[1]), B.ptr(c[2]), B.ptr(c[3]), B.ptr(c[4]),
+                                                ctx.max_depth, B.ptr(out), B.ptr(g), B.ptr(v_op), B.ptr(v_dp),
+                                                B.stream_handle(dev)), "gs_pixel_losses_bwd")
+        return (v_op.reshape(ctx.shapes[0]), v_dp.reshape(ctx.shapes[1]) if need_depth else None, None, None, None, None)
+
+
+def pixel_losses(opacity: Tensor, depth: Optional[Tensor] = None, sky_mask: Optional[Tensor] = None,
+                 valid_mask: Optional[Tensor] = None, lidar_depth: Optional[Tensor] = None, max_depth: float = 80.0):
+    """The per-pixel scalar terms of `compute_losses` in the reference's shipped configuration
+    (configs/omnire.yaml:24-31), in one pass (base.py:536-573, models/losses.py):
+
+        sky_bce          = binary_cross_entropy(opacity * valid, (1 - sky_mask) * valid, "mean")       (mask loss, "bce")
+        depth_l1         = DepthLoss("l1", normalize=False, use_inverse_depth=False)(depth, lidar_depth,
+                                                                                    (lidar_depth > 0) * valid)
+        opacity_entropy  = (-p * log p).mean(), p = clamp(opacity, 1e-6, 1 - 1e-6)
+
+    opacity [H,W] or [H,W,1]; depth [H,W,1]; masks / lidar_depth [H,W].  Returns a dict of 0-d tensors (terms whose
+    inputs are None are absent), differentiable w.r.t. opacity and depth.  The other variants the reference can be
+    configured with (safe_bce, l2 / smooth_l1, normalised or inverse depth, percentile clipping) are not built."""
+    n = opacity.numel()
+    for t in (depth, sky_mask, valid_mask, lidar_depth):
+        assert t is None or t.numel() == n, "all maps must have H*W elements"
+    assert lidar_depth is None or depth is not None
+    out = _PixelLosses.apply(opacity, depth, sky_mask, valid_mask, lidar_depth, max_depth)
+    res = {"opacity_entropy": out[3]}
+    if sky_mask is not None:
+        res["sky_bce"] = out[0]
+    if lidar_depth is not None:
+        res["depth_l1"] = out[1]
+    return res

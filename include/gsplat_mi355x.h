@@ -368,6 +368,21 @@ int gs_l1_ssim_fwd(int32_t H, int32_t W, const float* pred, const float* gt, con
 int gs_l1_ssim_bwd(int32_t H, int32_t W, const float* pred, const float* gt, const float* mask, const float* maps,
                    const float* g_out, float* v_pred, void* stream);
 
+/* The per-pixel scalar terms of compute_losses in the shipped configuration (R/configs/omnire.yaml:24-31), one pass:
+ *   out[0] = binary_cross_entropy(opacity * valid, (1 - sky_mask) * valid).mean()   (R/models/trainers/base.py:536-550)
+ *   out[1] = DepthLoss("l1", normalize=False, inverse=False, "mean_on_hit")(depth, lidar_depth, (lidar_depth > 0) * valid)
+ *            (R/models/losses.py:96-199, base.py:553-557), out[2] = number of pixels it averages over
+ *   out[3] = (-p log p).mean(), p = clamp(opacity, 1e-6, 1 - 1e-6)                  (base.py:568-573)
+ * over n = H*W pixels; valid_mask, sky_mask, lidar_depth may be NULL. */
+int64_t gs_pixel_losses_workspace_floats(void);
+int gs_pixel_losses_fwd(int64_t n, const float* opacity, const float* depth, const float* sky_mask,
+                        const float* valid_mask, const float* lidar_depth, float max_depth, float* workspace,
+                        int64_t workspace_floats, float* out /* [4] */, void* stream);
+int gs_pixel_losses_bwd(int64_t n, const float* opacity, const float* depth, const float* sky_mask,
+                        const float* valid_mask, const float* lidar_depth, float max_depth, const float* fwd_out,
+                        const float* g_out /* [4] device */, float* v_opacity, float* v_depth /* or NULL */,
+                        void* stream);
+
 /* ---- sky environment light (next to the path: SURVEY.md 8(f) rank 4) --------------------------------- */
 /* EnvLight.forward (R/models/modules.py:191-203): nvdiffrast.torch.texture(base[None], l, filter_mode='linear',
  * boundary_mode='cube') -- bilinear, seamless cube-map lookup (OpenGL face order +x,-x,+y,-y,+z,-z and orientation).

@@ -69,3 +69,51 @@ def test_l1_ssim_properties(gpu_device):
     assert torch.equal(c[1], a[1]) and not c[1].requires_grad
     with pytest.raises(AssertionError):
         l1_ssim(pred.to(dev)[:10], x[:10])
+
+
+def _reference_pixel_losses(opacity, depth, sky_masks, valid, lidar, max_depth=80.0):
+    """base.py:536-573 + models/losses.py (binary_cross_entropy "mean"; DepthLoss l1 / no normalisation / mean_on_hit)."""
+    gt_occupied_mask = (1.0 - sky_masks) * valid
+    pred_occupied_mask = opacity.squeeze() * valid
+    bce = torch.nn.functional.binary_cross_entropy(pred_occupied_mask, gt_occupied_mask, reduction="none").mean()
+    lidar_hit_mask = (lidar > 0).to(valid.dtype) * valid
+    pd, gd = depth.squeeze() * lidar_hit_mask, lidar.squeeze() * lidar_hit_mask
+    vm = (gd > 0.01) & (gd < max_depth) & (pd > 0.0001)
+    dl = torch.nn.functional.l1_loss(pd[vm], gd[vm], reduction="none").mean()
+    po = torch.clamp(opacity.squeeze(), 1e-6, 1 - 1e-6)
+    ent = (-po * torch.log(po)).mean()
+    return bce, dl, ent, int(vm.sum())
+
+
+@pytest.mark.parametrize("H,W", [(37, 53), (375, 1242)])
+def test_pixel_losses_match_reference_lines(gpu_device, H, W):
+    from gsplat.losses import pixel_losses
+
+    dev = gpu_device
+    g = torch.Generator().manual_seed(H)
+    opacity = torch.rand(H, W, 1, generator=g)
+    opacity[0, :5] = 0.0       # exact 0 / 1: the logs clamp at -100
+    opacity[1, :5] = 1.0
+    depth = torch.rand(H, W, 1, generator=g) * 90.0
+    depth[2, :7] = 0.0
+    sky = (torch.rand(H, W, generator=g) > 0.7).float()
+    valid = (torch.rand(H, W, generator=g) > 0.1).float()
+    lidar = torch.rand(H, W, generator=g) * 100.0 * (torch.rand(H, W, generator=g) > 0.8).float()  # sparse hits, some > 80
+    od, dd = opacity.double().requires_grad_(True), depth.double().requires_grad_(True)
+    bce_r, dl_r, ent_r, cnt = _reference_pixel_losses(od, dd, sky.double(), valid.double(), lidar.double())
+    (0.05 * bce_r + 0.01 * dl_r + 0.3 * ent_r).backward()
+    og, dg = opacity.to(dev).requires_grad_(True), depth.to(dev).requires_grad_(True)
+    res = pixel_losses(og, dg, sky.to(dev), valid.to(dev), lidar.to(dev))
+    assert cnt > 10
+    for name, ref in (("sky_bce", bce_r), ("depth_l1", dl_r), ("opacity_entropy", ent_r)):
+        got = float(res[name].detach())
+        assert abs(got - float(ref.detach())) < 1e-5 * max(1.0, abs(float(ref.detach()))), (name, got, float(ref.detach()))
+    (0.05 * res["sky_bce"] + 0.01 * res["depth_l1"] + 0.3 * res["opacity_entropy"]).backward()
+    for got, ref in ((og.grad, od.grad), (dg.grad, dd.grad)):
+        err = float((got.cpu().double() - ref).abs().max())
+        assert err < 1e-5 * float(ref.abs().max()) + 1e-12, (err, float(ref.abs().max()))
+    # terms without inputs are absent; an empty selection gives NaN like torch's mean of nothing
+    only = pixel_losses(opacity.to(dev))
+    assert set(only) == {"opacity_entropy"}
+    none_hit = pixel_losses(opacity.to(dev), depth.to(dev), None, None, torch.zeros(H, W, device=dev))
+    assert torch.isnan(none_hit["depth_l1"])
