@@ -144,8 +144,35 @@ def require_gpu(*tensors: torch.Tensor) -> torch.device:
     return dev
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_handle(device: torch.device) -> int:
+    """hipStream_t of torch's current stream on `device` (the raw accessor skips building a Stream object: this is
+    called once per native launch)."""
+    if _raw_stream is not None and device.index is not None:
+        return _raw_stream(device.index)
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class _NoGuard:
+    __slots__ = ()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_no_guard = _NoGuard()
+
+
+def device_guard(device: torch.device):
+    """`with device_guard(dev):` makes `dev` the current HIP device for a native launch; free when it already is."""
+    if device.index is None or device.index == torch.cuda.current_device():
+        return _no_guard
+    return torch.cuda.device(device)
 
 
 _side_streams = {}

@@ -33,7 +33,7 @@ class _SphericalHarmonics(torch.autograd.Function):
         m = masks.reshape(-1).to(torch.uint8).contiguous() if masks is not None else None
         n = d.shape[0]
         out = torch.empty(n, 3, device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev), B.timed("gs_sh_fwd", dev):
+        with B.device_guard(dev), B.timed("gs_sh_fwd", dev):
             B.check(B.lib().gs_sh_fwd(n, K, degree, B.ptr(d), B.ptr(c), B.ptr(m), B.ptr(out), B.stream_handle(dev)),
                     "gs_sh_fwd")
         ctx.save_for_backward(d, c, m if m is not None else torch.empty(0, device=dev))
@@ -52,7 +52,7 @@ class _SphericalHarmonics(torch.autograd.Function):
         v_coeffs = torch.empty(n, ctx.K, 3, device=dev, dtype=torch.float32)
         need_dirs = ctx.needs_input_grad[1]
         v_dirs = torch.empty(n, 3, device=dev, dtype=torch.float32) if need_dirs else None
-        with torch.cuda.device(dev), B.timed("gs_sh_bwd", dev):
+        with B.device_guard(dev), B.timed("gs_sh_bwd", dev):
             B.check(B.lib().gs_sh_bwd(n, ctx.K, ctx.degree, B.ptr(d), B.ptr(c), B.ptr(m), B.ptr(v), B.ptr(v_coeffs),
                                       B.ptr(v_dirs), B.stream_handle(dev)), "gs_sh_bwd")
         v_c = v_coeffs.reshape(ctx.coeff_shape) if ctx.needs_input_grad[2] else None
@@ -123,7 +123,7 @@ class _ProjectSplats(torch.autograd.Function):
         means2d = torch.empty(C, N, 2, device=dev, dtype=torch.float32)
         # rows with radii == 0 are never written nor read (as gsplat's torch.empty projection outputs)
         splats = torch.empty(C, N, B.GS_REC, device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev), B.timed("gs_projection_fwd", dev):
+        with B.device_guard(dev), B.timed("gs_projection_fwd", dev):
             B.check(B.lib().gs_projection_fwd(
                 ctypes.byref(params), B.ptr(means), B.ptr(quats), B.ptr(scales), B.ptr(opacities), B.ptr(viewmats),
                 B.ptr(Ks), B.ptr(campos), B.ptr(colors), B.ptr(radii), B.ptr(means2d), B.ptr(splats), B.ptr(tiles),
@@ -172,7 +172,7 @@ class _ProjectSplats(torch.autograd.Function):
         need_vm = ctx.needs_input_grad[5] or ctx.needs_input_grad[7]
         v_viewmats = torch.zeros(C, 4, 4, device=dev, dtype=torch.float32) if need_vm else None
         v_campos = torch.zeros(C, 3, device=dev, dtype=torch.float32) if (need_vm and campos is not None) else None
-        with torch.cuda.device(dev), B.timed("gs_projection_bwd", dev):
+        with B.device_guard(dev), B.timed("gs_projection_bwd", dev):
             B.check(B.lib().gs_projection_bwd(
                 ctypes.byref(p), B.ptr(means), B.ptr(quats), B.ptr(scales), B.ptr(opacities), B.ptr(viewmats),
                 B.ptr(Ks), B.ptr(campos), B.ptr(colors), B.ptr(radii), B.ptr(splats), v_means2d.data_ptr(), ld,
@@ -198,7 +198,7 @@ def exclusive_scan_i32(x: Tensor) -> Tuple[Tensor, Tensor]:
     total = torch.empty(1, device=dev, dtype=torch.int64)
     wsb = int(B.lib().gs_exclusive_scan_workspace_bytes(n))
     ws = torch.empty(max(wsb, 8), device=dev, dtype=torch.uint8)
-    with torch.cuda.device(dev), B.timed("gs_exclusive_scan_i32", dev):
+    with B.device_guard(dev), B.timed("gs_exclusive_scan_i32", dev):
         B.check(B.lib().gs_exclusive_scan_i32(B.ptr(x), B.ptr(out), n, B.ptr(total), B.ptr(ws), wsb,
                                               B.stream_handle(dev)), "gs_exclusive_scan_i32")
     return out, total
@@ -220,7 +220,7 @@ def radix_sort_pairs(keys: Tensor, vals: Tensor, end_bit: int, begin_bit: int = 
     wsb = int(B.lib().gs_radix_sort_workspace_bytes(n))
     ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
     in_b = ctypes.c_int32(0)
-    with torch.cuda.device(dev), B.timed(label, dev):
+    with B.device_guard(dev), B.timed(label, dev):
         B.check(B.lib().gs_radix_sort_pairs_u64_u32_ex(n, B.ptr(n_dev), begin_bit, end_bit, B.ptr(keys), B.ptr(vals),
                                                        B.ptr(kb), B.ptr(vb), B.ptr(ws), wsb, ctypes.byref(in_b),
                                                        B.stream_handle(dev)), "gs_radix_sort_pairs_u64_u32_ex")
@@ -247,7 +247,7 @@ def isect_tiles_from_splats(splats: Tensor, tiles_per_gauss: Tensor, tile_width:
     flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
     if n_isects == 0:
         return isect_ids, flatten_ids
-    with torch.cuda.device(dev), B.timed("gs_isect_emit", dev):
+    with B.device_guard(dev), B.timed("gs_isect_emit", dev):
         B.check(B.lib().gs_isect_emit(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
                                       B.ptr(cum), B.ptr(isect_ids), B.ptr(flatten_ids), B.stream_handle(dev)),
                 "gs_isect_emit")
@@ -290,7 +290,7 @@ class FrontSort:
     def redo(self) -> None:
         C, tw, th = self.geom
         dev = self.isect_ids.device
-        with torch.cuda.device(dev), B.timed("gs_isect_tile_sort_redo", dev):
+        with B.device_guard(dev), B.timed("gs_isect_tile_sort_redo", dev):
             B.check(B.lib().gs_isect_tile_sort_redo(C, tw, th, B.ptr(self.offsets), self.isect_ids.numel(),
                                                     B.ptr(self.order), B.ptr(self.n_long), B.ptr(self.redo_flags),
                                                     B.ptr(self.pairs), B.ptr(self.isect_ids), B.ptr(self.flatten_ids),
@@ -304,7 +304,7 @@ class FrontSort:
         self.complete = True
         C, tw, th = self.geom
         dev = self.isect_ids.device
-        with torch.cuda.device(dev):
+        with B.device_guard(dev):
             B.check(B.lib().gs_isect_tile_sort(C, tw, th, B.ptr(self.offsets), self.isect_ids.numel(),
                                                B.ptr(self.order), B.ptr(self.n_long), B.ptr(self.pairs),
                                                B.ptr(self.isect_ids), B.ptr(self.flatten_ids), B.stream_handle(dev)),
@@ -342,17 +342,17 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
         seg = int(lib.gs_isect_bin_slice_rows(N, n_slices))
         vis_list = torch.empty(C * n_slices * seg, 2, device=dev, dtype=torch.int64)
         vis_cnt = torch.empty(C * n_slices, device=dev, dtype=torch.int32)
-    with torch.cuda.device(dev), B.timed("gs_isect_bin_count", dev):
+    with B.device_guard(dev), B.timed("gs_isect_bin_count", dev):
         B.check(lib.gs_isect_bin_count(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss), n_slices,
                                        B.ptr(table), B.ptr(vis_list), B.ptr(vis_cnt), st), "gs_isect_bin_count")
-    with torch.cuda.device(dev), B.timed("gs_isect_bin_offsets", dev):
+    with B.device_guard(dev), B.timed("gs_isect_bin_offsets", dev):
         B.check(lib.gs_isect_bin_offsets(C, tile_width, tile_height, n_slices, B.ptr(table), B.ptr(counts),
                                          B.ptr(offsets), B.ptr(total), st), "gs_isect_bin_offsets")
     order = n_long = None
     if C * T <= 131072:
         order = torch.empty(C * T, device=dev, dtype=torch.int32)
         n_long = torch.empty(3, device=dev, dtype=torch.int32)  # size classes of the order
-        with torch.cuda.device(dev), B.timed("gs_raster_tile_order", dev):
+        with B.device_guard(dev), B.timed("gs_raster_tile_order", dev):
             B.check(lib.gs_raster_tile_order(C * T, None, 0, B.ptr(counts), B.ptr(order), B.ptr(n_long), st),
                     "gs_raster_tile_order")
     n_isects = int(total.item())  # the one host sync of the pipeline (gsplat has the same one)
@@ -361,7 +361,7 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
     if n_isects == 0:
         return isect_ids, flatten_ids, offsets, None, None
     pairs = torch.empty(n_isects, device=dev, dtype=torch.int64)
-    with torch.cuda.device(dev), B.timed("gs_isect_bin_scatter", dev):
+    with B.device_guard(dev), B.timed("gs_isect_bin_scatter", dev):
         if vis_list is not None:
             B.check(lib.gs_isect_bin_scatter_regions(C, N, tile_width, tile_height, n_slices, group, regions,
                                                      B.ptr(vis_list), B.ptr(vis_cnt), B.ptr(table), B.ptr(offsets),
@@ -372,13 +372,13 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
                     "gs_isect_bin_scatter")
     if front and order is not None:
         # `counts` (the list lengths) becomes sorted_counts: the front kernel overwrites the long tiles' entries
-        with torch.cuda.device(dev), B.timed("gs_isect_tile_sort", dev):
+        with B.device_guard(dev), B.timed("gs_isect_tile_sort", dev):
             B.check(lib.gs_isect_tile_sort_front(C, tile_width, tile_height, B.ptr(offsets), n_isects, B.ptr(order),
                                                  B.ptr(n_long), FRONT_K_TARGET, B.ptr(pairs), B.ptr(isect_ids),
                                                  B.ptr(flatten_ids), B.ptr(counts), st), "gs_isect_tile_sort_front")
         fs = FrontSort((C, tile_width, tile_height), offsets, order, n_long, pairs, isect_ids, flatten_ids, counts)
         return isect_ids, flatten_ids, offsets, order, fs
-    with torch.cuda.device(dev), B.timed("gs_isect_tile_sort", dev):
+    with B.device_guard(dev), B.timed("gs_isect_tile_sort", dev):
         B.check(lib.gs_isect_tile_sort(C, tile_width, tile_height, B.ptr(offsets), n_isects, B.ptr(order), B.ptr(n_long),
                                        B.ptr(pairs), B.ptr(isect_ids), B.ptr(flatten_ids), st), "gs_isect_tile_sort")
     return isect_ids, flatten_ids, offsets, order, None
@@ -387,7 +387,7 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
 def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
     dev = B.require_gpu(isect_ids)
     offsets = torch.empty(n_cameras, tile_height, tile_width, device=dev, dtype=torch.int32)
-    with torch.cuda.device(dev), B.timed("gs_isect_offset_encode", dev):
+    with B.device_guard(dev), B.timed("gs_isect_offset_encode", dev):
         B.check(B.lib().gs_isect_offset_encode(isect_ids.numel(), B.ptr(isect_ids.contiguous()), n_cameras, tile_width,
                                                tile_height, B.ptr(offsets), B.stream_handle(dev)),
                 "gs_isect_offset_encode")
@@ -404,7 +404,7 @@ def launch_raster_fwd(splats, offsets, flatten_ids, order, fs, bg, geom, rc, ra,
         fs = None
 
     def raster(redo_pass: int) -> None:
-        with torch.cuda.device(dev), B.timed("gs_rasterize_fwd" if not redo_pass else "gs_rasterize_fwd_redo", dev):
+        with B.device_guard(dev), B.timed("gs_rasterize_fwd" if not redo_pass else "gs_rasterize_fwd_redo", dev):
             B.check(B.lib().gs_rasterize_fwd(C, width, height, tile_size, channels, B.ptr(splats), B.ptr(offsets),
                                              B.ptr(flatten_ids), n_isects, B.ptr(bg), int(ed), B.ptr(rc), B.ptr(ra),
                                              B.ptr(last_ids), B.ptr(order), B.ptr(work),
@@ -487,7 +487,7 @@ class _RasterizeSplats(torch.autograd.Function):
             work = torch.empty(n_tiles, device=dev, dtype=torch.int32) if ctx.needs_input_grad[0] else None
         if n_isects > 0 and n_tiles <= 131072 and order is None:
             order = torch.empty(n_tiles, device=dev, dtype=torch.int32)
-            with torch.cuda.device(dev), B.timed("gs_raster_tile_order", dev):
+            with B.device_guard(dev), B.timed("gs_raster_tile_order", dev):
                 B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, None, B.ptr(order), None,
                                                      B.stream_handle(dev)), "gs_raster_tile_order")
         launch_raster_fwd(splats, offsets, flatten_ids, order, fs, bg, (C, N, width, height, tile_size, channels, ed),
@@ -498,7 +498,7 @@ class _RasterizeSplats(torch.autograd.Function):
         if work is not None:
             # (a tensor of its own: `order` and its size classes still describe the sort launches of `fs`)
             order_bwd = torch.empty_like(order)
-            with torch.cuda.device(dev), B.timed("gs_raster_tile_order", dev):
+            with B.device_guard(dev), B.timed("gs_raster_tile_order", dev):
                 B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, B.ptr(work), B.ptr(order_bwd),
                                                      None, B.stream_handle(dev)), "gs_raster_tile_order")
         ctx.tile_order = order_bwd
@@ -526,7 +526,7 @@ class _RasterizeSplats(torch.autograd.Function):
             torch.cuda.current_stream(dev).wait_event(ctx.v_ready)
         else:
             v_splats = torch.zeros_like(splats)
-        with torch.cuda.device(dev), B.timed("gs_rasterize_bwd", dev):
+        with B.device_guard(dev), B.timed("gs_rasterize_bwd", dev):
             B.check(B.lib().gs_rasterize_bwd(C, width, height, tile_size, channels, B.ptr(splats), B.ptr(offsets),
                                              B.ptr(flatten_ids), flatten_ids.numel(), B.ptr(bg), ed, B.ptr(rc),
                                              B.ptr(ra), B.ptr(last_ids), B.ptr(v_rc), B.ptr(v_ra), int(absgrad),

@@ -45,7 +45,7 @@ def accumulate_stats(meta: Dict, state: DensifyState, absgrad: bool = True, batc
         state.vis_counts = torch.empty(N, device=dev, dtype=torch.float32)
         state.max_2Dsize = torch.empty(N, device=dev, dtype=torch.float32)
     W, H = meta["width"], meta["height"]
-    with torch.cuda.device(dev):
+    with B.device_guard(dev):
         B.check(B.lib().gs_densify_accumulate(C, N, B.ptr(radii), grad.data_ptr(), ld, W / 2.0 * batch_size,
                                               H / 2.0 * batch_size, 1.0 / float(max(W, H)), int(first),
                                               B.ptr(state.xys_grad_norm), B.ptr(state.vis_counts),
@@ -109,7 +109,7 @@ def refine_gaussians(params: Dict[str, Tensor], state: Optional[DensifyState], c
     flags = torch.empty(n, device=dev, dtype=torch.uint8)
     counts = torch.empty(4 * n + 1, device=dev, dtype=torch.int32)
     L, stream = B.lib(), B.stream_handle(dev)
-    with torch.cuda.device(dev):
+    with B.device_guard(dev):
         B.check(L.gs_refine_decide(n, smode, int(cfg.do_densify), int(cfg.do_cull), cfg.densify_grad_thresh,
                                    cfg.densify_size_thresh * cfg.scene_scale, neg(cfg.split_screen_size),
                                    cfg.cull_alpha_thresh, neg(cfg.cull_scale_thresh, cfg.scene_scale),
@@ -138,7 +138,7 @@ def refine_gaussians(params: Dict[str, Tensor], state: Optional[DensifyState], c
                                         stream), "gs_refine_gather_rows")
         return out
 
-    with torch.cuda.device(dev):
+    with B.device_guard(dev):
         if n_out > 0:  # (everything culled: the outputs are empty and there is nothing to plan)
             B.check(L.gs_refine_plan(n, ns, B.ptr(flags), B.ptr(scan), B.ptr(src), B.ptr(kinds), B.ptr(sidx), stream),
                     "gs_refine_plan")

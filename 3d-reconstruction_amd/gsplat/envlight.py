@@ -27,7 +27,7 @@ class _CubeTexture(torch.autograd.Function):
         rot_c = B.f32c(rot).reshape(9) if rot is not None else None
         n = dirs_c.shape[0]
         out = torch.empty(n, C, device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev), B.timed("gs_cube_texture_fwd", dev):
+        with B.device_guard(dev), B.timed("gs_cube_texture_fwd", dev):
             B.check(B.lib().gs_cube_texture_fwd(n, R, C, B.ptr(base_c), B.ptr(dirs_c), B.ptr(rot_c), B.ptr(out),
                                                 B.stream_handle(dev)), "gs_cube_texture_fwd")
         ctx.geom = (n, R, C, tuple(base.shape))
@@ -43,7 +43,7 @@ class _CubeTexture(torch.autograd.Function):
         dev = dirs_c.device
         v = B.f32c(v_out).reshape(n, C)
         v_tex = torch.zeros(shape, device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev), B.timed("gs_cube_texture_bwd", dev):
+        with B.device_guard(dev), B.timed("gs_cube_texture_bwd", dev):
             B.check(B.lib().gs_cube_texture_bwd(n, R, C, B.ptr(dirs_c), B.ptr(rot_c), B.ptr(v), B.ptr(v_tex),
                                                 B.stream_handle(dev)), "gs_cube_texture_bwd")
         return v_tex, None, None

@@ -30,7 +30,7 @@ class _L1Ssim(torch.autograd.Function):
         ws = torch.empty(nws, device=dev, dtype=torch.float32)
         maps = torch.empty((H - 10) * (W - 10) * 9, device=dev, dtype=torch.float32) if need else None
         out = torch.empty(2, device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev), B.timed("gs_l1_ssim_fwd", dev):
+        with B.device_guard(dev), B.timed("gs_l1_ssim_fwd", dev):
             B.check(L.gs_l1_ssim_fwd(H, W, B.ptr(pred_c), B.ptr(gt_c), B.ptr(mask_c), B.ptr(maps), B.ptr(ws), nws,
                                      B.ptr(out), B.stream_handle(dev)), "gs_l1_ssim_fwd")
         ctx.has_mask = mask is not None
@@ -46,7 +46,7 @@ class _L1Ssim(torch.autograd.Function):
         H, W = pred.shape[0], pred.shape[1]
         g = B.f32c(g_out)
         v = torch.empty_like(pred)
-        with torch.cuda.device(dev), B.timed("gs_l1_ssim_bwd", dev):
+        with B.device_guard(dev), B.timed("gs_l1_ssim_bwd", dev):
             B.check(B.lib().gs_l1_ssim_bwd(H, W, B.ptr(pred), B.ptr(gt), B.ptr(mask), B.ptr(maps), B.ptr(g), B.ptr(v),
                                            B.stream_handle(dev)), "gs_l1_ssim_bwd")
         return v, None, None, None
@@ -72,7 +72,7 @@ class _PixelLosses(torch.autograd.Function):
         nws = int(L.gs_pixel_losses_workspace_floats())
         ws = torch.empty(nws, device=dev, dtype=torch.float32)
         out = torch.empty(4, device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev), B.timed("gs_pixel_losses_fwd", dev):
+        with B.device_guard(dev), B.timed("gs_pixel_losses_fwd", dev):
             B.check(L.gs_pixel_losses_fwd(n, B.ptr(c[0]), B.ptr(c[1]), B.ptr(c[2]), B.ptr(c[3]), B.ptr(c[4]),
                                           float(max_depth), B.ptr(ws), nws, B.ptr(out), B.stream_handle(dev)),
                     "gs_pixel_losses_fwd")
@@ -93,7 +93,7 @@ class _PixelLosses(torch.autograd.Function):
         need_depth = c[1] is not None and ctx.needs_input_grad[1]
         v_op = torch.empty(n, device=dev, dtype=torch.float32)
         v_dp = torch.empty(n, device=dev, dtype=torch.float32) if need_depth else None
-        with torch.cuda.device(dev), B.timed("gs_pixel_losses_bwd", dev):
+        with B.device_guard(dev), B.timed("gs_pixel_losses_bwd", dev):
             B.check(B.lib().gs_pixel_losses_bwd(n, B.ptr(c[0]), B.ptr(c[1]), B.ptr(c[2]), B.ptr(c[3]), B.ptr(c[4]),
                                                 ctx.max_depth, B.ptr(out), B.ptr(g), B.ptr(v_op), B.ptr(v_dp),
                                                 B.stream_handle(dev)), "gs_pixel_losses_bwd")

@@ -82,7 +82,7 @@ class _Collect(torch.autograd.Function):
         stream = B.stream_handle(dev)
         saved = []
         row = 0
-        with torch.cuda.device(dev):
+        with B.device_guard(dev):
             for ci, (n, kr, deg, smode, has_mask) in enumerate(spec):
                 means, dc, rest, opac, scales, quats, mask = tensors[7 * ci:7 * ci + 7]
                 means, dc, rest, opac, scales, quats = (B.f32c(t.detach()) for t in (means, dc, rest, opac, scales, quats))
@@ -110,7 +110,7 @@ class _Collect(torch.autograd.Function):
         grads: List[Optional[Tensor]] = []
         row = 0
         si = 0
-        with torch.cuda.device(dev):
+        with B.device_guard(dev):
             for ci, (n, kr, deg, smode, has_mask) in enumerate(ctx.spec):
                 means, dc, opac, scales, quats = saved[si:si + 5]
                 si += 5

@@ -370,7 +370,7 @@ def _pack_meta(splats: Tensor, means2d: Tensor, radii: Tensor):
     dev = radii.device
     C, N = radii.shape
     vis = torch.empty(C * N, device=dev, dtype=torch.int32)
-    with torch.cuda.device(dev):
+    with B.device_guard(dev):
         B.check(B.lib().gs_mark_visible(C * N, B.ptr(radii), B.ptr(vis), B.stream_handle(dev)), "gs_mark_visible")
     cum, total = W.exclusive_scan_i32(vis)
     nnz = int(total.item())
@@ -380,7 +380,7 @@ def _pack_meta(splats: Tensor, means2d: Tensor, radii: Tensor):
     m2d_p = torch.empty(nnz, 2, device=dev, dtype=torch.float32)
     depths_p = torch.empty(nnz, device=dev, dtype=torch.float32)
     conics_p = torch.empty(nnz, 3, device=dev, dtype=torch.float32)
-    with torch.cuda.device(dev):
+    with B.device_guard(dev):
         if nnz > 0:  # (nothing visible: the empty outputs have no storage to point at)
             B.check(B.lib().gs_compact_visible(C, N, B.ptr(radii), B.ptr(cum), B.ptr(splats.detach()),
                                                B.ptr(means2d.detach()), B.ptr(camera_ids), B.ptr(gaussian_ids),
