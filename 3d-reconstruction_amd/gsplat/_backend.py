@@ -65,6 +65,8 @@ _SIGNATURES = {
     "gs_raster_tile_order": (ctypes.c_int, [c_int32, _P, c_int64, _P, _P, _P, _P]),
     "gs_densify_accumulate": (ctypes.c_int, [c_int32, c_int32, _P, _P, c_int64, c_float, c_float, c_float, c_int32,
                                              _P, _P, _P, _P]),
+    "gs_rigid_transform_fwd": (ctypes.c_int, [c_int64, c_int32] + [_P] * 8),
+    "gs_rigid_transform_bwd": (ctypes.c_int, [c_int64, c_int32] + [_P] * 11),
     "gs_activate_fwd": (ctypes.c_int, [c_int64, c_int32, c_int32] + [_P] * 7 + [c_int32] + [_P] * 9),
     "gs_activate_bwd": (ctypes.c_int, [c_int64, c_int32, c_int32] + [_P] * 6 + [c_int32] + [_P] * 12),
     "gs_refine_decide": (ctypes.c_int, [c_int64, c_int32, c_int32, c_int32] + [c_float] * 6 + [_P] * 8),

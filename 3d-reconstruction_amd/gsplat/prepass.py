@@ -176,3 +176,59 @@ def collect_gaussians(classes: Sequence[GaussianClass], camtoworld: Tensor, *, f
     if check_finite:
         flag.check(step)
     return gs_dict, torch.cat(labels, dim=0), flag
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# rigid nodes: instance-pose transform (nodes/rigid.py:403-470)
+
+class _RigidTransform(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, quats, point_ids, inst_quats, inst_trans):
+        dev = B.require_gpu(means, quats, point_ids, inst_quats, inst_trans)
+        n, n_inst = means.shape[0], inst_quats.shape[0]
+        means, quats = B.f32c(means), B.f32c(quats)
+        inst_quats, inst_trans = B.f32c(inst_quats), B.f32c(inst_trans)
+        o_means = torch.empty(n, 3, device=dev, dtype=torch.float32)
+        o_quats = torch.empty(n, 4, device=dev, dtype=torch.float32)
+        with B.device_guard(dev), B.timed("gs_rigid_transform_fwd", dev):
+            B.check(B.lib().gs_rigid_transform_fwd(n, n_inst, B.ptr(means), B.ptr(quats), B.ptr(point_ids),
+                                                   B.ptr(inst_quats), B.ptr(inst_trans), B.ptr(o_means), B.ptr(o_quats),
+                                                   B.stream_handle(dev)), "gs_rigid_transform_fwd")
+        ctx.save_for_backward(means, quats, point_ids, inst_quats)
+        ctx.set_materialize_grads(False)
+        return o_means, o_quats
+
+    @staticmethod
+    def backward(ctx, v_means, v_quats):
+        means, quats, point_ids, inst_quats = ctx.saved_tensors
+        dev = means.device
+        n, n_inst = means.shape[0], inst_quats.shape[0]
+        need = ctx.needs_input_grad
+        v_means = B.f32c(v_means) if v_means is not None else None
+        v_quats = B.f32c(v_quats) if v_quats is not None else None
+        g_means = torch.empty_like(means) if need[0] else None
+        g_quats = torch.empty_like(quats) if need[1] else None
+        g_iq = torch.zeros_like(inst_quats) if need[3] else None
+        g_it = torch.zeros(n_inst, 3, device=dev, dtype=torch.float32) if need[4] else None
+        with B.device_guard(dev), B.timed("gs_rigid_transform_bwd", dev):
+            B.check(B.lib().gs_rigid_transform_bwd(n, n_inst, B.ptr(means), B.ptr(quats), B.ptr(point_ids),
+                                                   B.ptr(inst_quats), B.ptr(v_means), B.ptr(v_quats), B.ptr(g_means),
+                                                   B.ptr(g_quats), B.ptr(g_iq), B.ptr(g_it), B.stream_handle(dev)),
+                    "gs_rigid_transform_bwd")
+        return g_means, g_quats, None, g_iq, g_it
+
+
+def rigid_transform(means: Tensor, quats: Tensor, point_ids: Tensor, inst_quats: Tensor, inst_trans: Tensor,
+                    validate: bool = False) -> Tuple[Tensor, Tensor]:
+    """RigidNodes.transform_means + transform_quats (nodes/rigid.py:403-470) for the current frame's pose rows
+    `inst_quats [I,4]`, `inst_trans [I,3]` (after the caller's optional test-set interpolation, :411-450) and the
+    per-point instance ids `point_ids [n]` or `[n,1]` (long).  Returns (world_means [n,3], world_quats [n,4]); the
+    world quaternions are normalised later by `collect_gaussians` (rigid.py:495).  Differentiable w.r.t. means, quats
+    and both pose tensors.  `validate=True` checks the ids on the host (one synchronisation)."""
+    n = means.shape[0]
+    assert means.shape == (n, 3) and quats.shape == (n, 4) and point_ids.numel() == n
+    assert inst_quats.dim() == 2 and inst_quats.shape[1] == 4 and inst_trans.shape == (inst_quats.shape[0], 3)
+    pid = point_ids.reshape(n).to(torch.int64).contiguous()
+    if validate and n > 0:
+        assert int(pid.min()) >= 0 and int(pid.max()) < inst_quats.shape[0], "point_ids out of range"
+    return _RigidTransform.apply(means, quats, pid, inst_quats, inst_trans)

@@ -284,6 +284,17 @@ int gs_compact_visible(int32_t C, int32_t N, const int32_t* radii, const int32_t
                        float* conics_packed,                          /* out [nnz,3] */
                        void* stream);
 
+/* Instance-pose transform of the rigid nodes' points (R/models/nodes/rigid.py:403-470), per point with p = point_ids[i]:
+ *   out_means = quat_to_rotmat(a_p / |a_p|) means + t_p,   out_quats = (a_p / |a_p|) (x) (quats / |quats|)   (Hamilton, wxyz)
+ * with a = inst_quats [n_inst,4], t = inst_trans [n_inst,3] (the frame's pose rows).  The backward accumulates the pose
+ * gradients into g_inst_quats / g_inst_trans (zeroed by the caller); g_* and v_* may be NULL. */
+int gs_rigid_transform_fwd(int64_t n, int32_t n_inst, const float* means, const float* quats, const int64_t* point_ids,
+                           const float* inst_quats, const float* inst_trans, float* out_means, float* out_quats,
+                           void* stream);
+int gs_rigid_transform_bwd(int64_t n, int32_t n_inst, const float* means, const float* quats, const int64_t* point_ids,
+                           const float* inst_quats, const float* v_world_means, const float* v_world_quats,
+                           float* g_means, float* g_quats, float* g_inst_quats, float* g_inst_trans, void* stream);
+
 /* ---- densification statistics (next to the path: SURVEY.md 8(f) rank 2) -------------------------- */
 /* One fused pass of BasicTrainer.postprocess_per_train_step's gradient scaling (R/models/trainers/base.py:279-297)
  * + VanillaGaussians.after_train (R/models/gaussians/vanilla.py:154-182).  grad2d points at the 2-float screen-space

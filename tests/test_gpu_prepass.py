@@ -180,3 +180,59 @@ def test_prepass_feeds_rasterization(gpu_device):
             assert a[k] is not None and torch.isfinite(a[k]).all(), k
             rel = float((a[k].double() - b[k].double()).norm() / (b[k].double().norm() + 1e-30))
             assert rel < 1e-4, (k, rel)
+
+
+def _ref_quat_to_rotmat(quat):
+    """utils/geometry.py:116-152."""
+    quat = quat / torch.norm(quat, dim=-1, keepdim=True)
+    w, x, y, z = quat[..., 0], quat[..., 1], quat[..., 2], quat[..., 3]
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z),
+                        1 - 2 * (x * x + z * z), 2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x),
+                        1 - 2 * (x * x + y * y)], dim=-1).reshape(*quat.shape[:-1], 3, 3)
+
+
+def _ref_quat_mult(q1, q2):
+    """models/gaussians/basics.py:64-74."""
+    w1, x1, y1, z1 = q1.T
+    w2, x2, y2, z2 = q2.T
+    return torch.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                        w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2]).T
+
+
+@pytest.mark.parametrize("grouped", [True, False])
+def test_rigid_transform_matches_reference_lines(gpu_device, grouped):
+    """nodes/rigid.py:403-470 (transform_means / transform_quats, no test-set interpolation) in fp64 vs the kernel:
+    outputs and the gradients of means, quats, instances_quats[frame], instances_trans[frame] (1e-5 relative)."""
+    from gsplat.prepass import rigid_transform
+
+    dev = gpu_device
+    n, n_inst = 20_003, 37
+    g = torch.Generator().manual_seed(3)
+    means, quats = torch.randn(n, 3, generator=g) * 2, torch.randn(n, 4, generator=g)
+    iq, it = torch.randn(n_inst, 4, generator=g) * 1.3, torch.randn(n_inst, 3, generator=g) * 10
+    pid = torch.randint(0, n_inst, (n, 1), generator=g)
+    if grouped:
+        pid = pid.sort(dim=0).values  # points of an instance contiguous, as RigidNodes builds them
+    wm_w, wq_w = torch.randn(n, 3, generator=g), torch.randn(n, 4, generator=g)
+
+    ref = [t.double().requires_grad_(True) for t in (means, quats, iq, it)]
+    quat_act = lambda x: x / x.norm(dim=-1, keepdim=True)
+    rot = _ref_quat_to_rotmat(quat_act(ref[2]))[pid[..., 0]]
+    wm = torch.bmm(rot, ref[0].unsqueeze(-1)).squeeze(-1) + ref[3][pid[..., 0]]
+    wq = _ref_quat_mult(quat_act(ref[2][pid[..., 0]]), quat_act(ref[1]))
+    ((wm * wm_w.double()).sum() + (wq * wq_w.double()).sum()).backward()
+
+    got = [t.to(dev).requires_grad_(True) for t in (means, quats, iq, it)]
+    gm, gq = rigid_transform(got[0], got[1], pid.to(dev), got[2], got[3], validate=True)
+    assert torch.allclose(gm.detach().cpu().double(), wm.detach(), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(gq.detach().cpu().double(), wq.detach(), rtol=1e-5, atol=1e-6)
+    ((gm * wm_w.to(dev)).sum() + (gq * wq_w.to(dev)).sum()).backward()
+    for name, a, b in zip(("means", "quats", "inst_quats", "inst_trans"), got, ref):
+        rel = float((a.grad.cpu().double() - b.grad).norm() / b.grad.norm())
+        assert rel < 1e-5, (name, rel)
+    # only the world means feed the loss (the other upstream gradient is absent)
+    got2 = [t.to(dev).requires_grad_(True) for t in (means, quats, iq, it)]
+    gm2, _ = rigid_transform(got2[0], got2[1], pid.to(dev), got2[2], got2[3])
+    gm2.sum().backward()
+    assert torch.allclose(got2[3].grad.cpu(), torch.bincount(pid[..., 0], minlength=n_inst).float()[:, None].expand(-1, 3))
+    assert float(got2[1].grad.abs().max()) == 0.0
