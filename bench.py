@@ -217,6 +217,15 @@ def main():
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": measured_traffic(dom, N, C, H, W),
                         "algorithmic_bytes_per_launch": bytes_[dom], "avg_launch_ms": round(per_launch_ms, 4)}
+        # the same figure for every stage that has algorithmic bytes (pre-pass launch averages; the sort chain and the
+        # redo launches are folded into their stage's entry point)
+        per_kernel = {}
+        for k, nbytes in bytes_.items():
+            ms_k = sum(v[1] * v[0] / 3 for kk, v in kern_all.items() if kk == k or kk.startswith(k + "_"))
+            if ms_k > 0:
+                gbs = nbytes / (ms_k * 1e-3) / 1e9
+                per_kernel[k] = {"ms": round(ms_k, 4), "algorithmic_bytes": nbytes, "GB/s": round(gbs, 1),
+                                 "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
         total_bytes = sum(bytes_.values())
         out = {
             "metric": "Mpix/s fwd+bwd, 1M Gaussians @375x1242x5 cams", "value": round(value, 3), "unit": "Mpix/s",
@@ -231,7 +240,7 @@ def main():
             "roofline": roofline,
             "step_hbm_floor": {"algorithmic_bytes_per_step": total_bytes,
                                "frac_of_hbm_peak": round(total_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
-            "kernels_ms": kern_ms, "kernel_calls_per_step": kern_calls,
+            "kernels_ms": kern_ms, "kernel_calls_per_step": kern_calls, "kernel_rooflines": per_kernel,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_threads)
