@@ -7,12 +7,16 @@
 //                            histogram over that camera's tiles  ->  table[camera][slice][tile]
 //   2. gs_isect_bin_offsets  per tile: exclusive prefix over the slices, total per tile; exclusive scan of the totals
 //                            = isect_offsets (A.4's lower bounds, no search needed), last value = n_isects
-//   3. gs_isect_bin_scatter  same walk; an LDS cursor per tile (offset + slice prefix) hands every hit its slot in the
-//                            tile's segment; writes (depth bits, flat row id) pairs, order inside a segment arbitrary
-//   4. gs_isect_tile_sort    one workgroup per tile: stable LSD radix sort of the segment by depth IN LDS (4 x 8 bits,
-//                            wave64 match-any ranking), then an odd-even fix-up that orders equal depths by row id,
-//                            then writes the final isect_ids / flatten_ids.  Segments beyond the LDS capacity run the
-//                            same code on global scratch.
+//   3. gs_isect_bin_scatter_regions   a workgroup owns a band of tile rows and a group of slices, walks the visible
+//                            lists the count pass left (16 B per visible row) clipped to its band; an LDS cursor per
+//                            tile (offset + slice prefix) hands every hit its slot in the tile's segment; writes
+//                            (depth bits, flat row id) pairs, order inside a segment arbitrary.  (gs_isect_bin_scatter:
+//                            the same by row slice, from the records, for callers without the lists.)
+//   4. gs_isect_tile_sort    one workgroup per tile segment, sorted IN LDS on the 64-bit (depth, row id) key: counting
+//                            partition on a linear-depth bucket + per-bucket insertion sort, LSD radix fallback for
+//                            crowded buckets; writes the final isect_ids / flatten_ids.  Segments beyond the LDS
+//                            capacity run the same code on global scratch.  gs_isect_tile_sort_front sorts only the
+//                            leading entries of long segments (see "front sort" below).
 // Bit-exact with A.3/A.4 (same keys, same order, same offsets); the atomics only decide the order INSIDE a tile
 // segment before step 4, which the sort then fixes completely.  HBM traffic: 2 reads of the visible records,
 // one 8-B write + read and one 12-B write per intersection.
