@@ -98,24 +98,36 @@ __global__ __launch_bounds__(BIN_THREADS) void isect_bin_kernel(int32_t N, int32
   const bool keep = !SCATTER && vis_list != nullptr;
   uint4* seg = keep ? vis_list + ((int64_t)c * n_slices + slice) * rows_per_slice : nullptr;
   int written = 0;
-  int cntg = (n0 + tid < n1) ? tiles_per_gauss[(int64_t)c * N + n0 + tid] : 0;
+  // software pipeline over the 1024-row steps: a step's tile counts are loaded two steps ahead and its visible rows'
+  // records one step ahead, so the gathers of step k+1 are in flight while step k is queued and drained
+  auto count_of = [&](int row) { return row < n1 ? tiles_per_gauss[(int64_t)c * N + row] : 0; };
+  int cntg = count_of(n0 + tid), cnt_next = count_of(n0 + BIN_THREADS + tid);
+  float4 r3 = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t dbits = 0u;
+  if (cntg > 0) {
+    const int64_t i0 = (int64_t)c * N + n0 + tid;
+    r3 = reinterpret_cast<const float4*>(splats + i0 * REC)[3];
+    if (SCATTER || keep) dbits = (uint32_t)__float_as_int(splats[i0 * REC + 10]);
+  }
   for (int nb = n0; nb < n1; nb += BIN_THREADS) {
     const int64_t idx = (int64_t)c * N + nb + tid;
     const bool vis = cntg > 0;
-    // next block's counts are in flight while this one is queued
-    const int nn = nb + BIN_THREADS + tid;
-    const int cnt_next = (nn < n1) ? tiles_per_gauss[(int64_t)c * N + nn] : 0;
+    float4 r3_next = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t dbits_next = 0u;
+    if (cnt_next > 0) {
+      const int64_t i1 = idx + BIN_THREADS;
+      r3_next = reinterpret_cast<const float4*>(splats + i1 * REC)[3];
+      if (SCATTER || keep) dbits_next = (uint32_t)__float_as_int(splats[i1 * REC + 10]);
+    }
+    const int cnt_nn = count_of(nb + 2 * BIN_THREADS + tid);
     const unsigned long long vm = __ballot(vis);
     int qbase = 0;
     if (lane == 0 && vm) qbase = atomicAdd(&q_n, __popcll(vm));
     qbase = __shfl(qbase, 0);
-    if (vis) {
-      const float4 r3 = reinterpret_cast<const float4*>(splats + idx * REC)[3];
-      const uint32_t dbits = (SCATTER || keep) ? (uint32_t)__float_as_int(splats[idx * REC + 10]) : 0u;
+    if (vis)
       q[qbase + __popcll(vm & lt_mask)] =
           make_uint4((uint32_t)idx, (uint32_t)__float_as_int(r3.y), (uint32_t)__float_as_int(r3.z), dbits);
-    }
-    cntg = cnt_next;
+    cntg = cnt_next; cnt_next = cnt_nn; r3 = r3_next; dbits = dbits_next;
     // a block appends at most BIN_THREADS entries, so draining every QCAP/256 blocks (a data-independent, workgroup-uniform
     // decision) can never overflow the queue
     const int it = (nb - n0) / BIN_THREADS;
