@@ -236,3 +236,37 @@ def test_rigid_transform_matches_reference_lines(gpu_device, grouped):
     gm2.sum().backward()
     assert torch.allclose(got2[3].grad.cpu(), torch.bincount(pid[..., 0], minlength=n_inst).float()[:, None].expand(-1, 3))
     assert float(got2[1].grad.abs().max()) == 0.0
+
+
+def test_rigid_class_chains_into_collect_and_render(gpu_device):
+    """RigidNodes.get_gaussians (rigid.py:472-517) composed from the two fused ops: instance poses -> rigid_transform ->
+    collect_gaussians (validity mask on the opacities) -> rasterization; the loss gradient reaches the pose rows."""
+    import synth_scene
+    from gsplat.prepass import GaussianClass, collect_gaussians, rigid_transform
+    from gsplat.rendering import rasterization
+
+    dev = gpu_device
+    W, H, n, n_inst = 128, 80, 4000, 5
+    g = torch.Generator().manual_seed(5)
+    raw = _make_class(n, 16, 3, 3, 31, mask=True, label=1)
+    raw["means"] = torch.randn(n, 3, generator=g) * 0.5            # object-frame points
+    raw["scales"] = raw["scales"] + 0.3
+    raw = {k: (v.to(dev).requires_grad_(True) if k in _PARAMS else (v.to(dev) if torch.is_tensor(v) else v))
+           for k, v in raw.items()}
+    pid = torch.randint(0, n_inst, (n, 1), generator=g).sort(dim=0).values.to(dev)
+    inst_q = torch.randn(n_inst, 4, generator=g).to(dev).requires_grad_(True)
+    inst_t = (torch.tensor([[0.0, 0.0, 8.0]]) + torch.randn(n_inst, 3, generator=g) * 2.0).to(dev).requires_grad_(True)
+    vm = torch.eye(4, device=dev)[None]
+    Ks = torch.tensor([[W / 2.0, 0, W / 2.0], [0, W / 2.0, H / 2.0], [0, 0, 1.0]], device=dev)[None]
+    wm, wq = rigid_transform(raw["means"], raw["quats"], pid, inst_q, inst_t)
+    cls = GaussianClass(**{**raw, "means": wm, "quats": wq})
+    gs, labels, flag = collect_gaussians([cls], torch.eye(4, device=dev))
+    rc, ra, info = rasterization(means=gs["_means"], quats=gs["_quats"], scales=gs["_scales"],
+                                 opacities=gs["_opacities"].squeeze(), colors=gs["_rgbs"], viewmats=vm, Ks=Ks, width=W,
+                                 height=H, packed=False, absgrad=True, near_plane=0.1, render_mode="RGB+ED")
+    flag.check()
+    assert float(ra.detach().sum()) > 10.0 and int(labels[0]) == 1
+    (rc.square().sum() + ra.sum()).backward()
+    for name, t in (("inst_quats", inst_q), ("inst_trans", inst_t), ("means", raw["means"]), ("quats", raw["quats"]),
+                    ("features_rest", raw["features_rest"])):
+        assert t.grad is not None and torch.isfinite(t.grad).all() and float(t.grad.abs().sum()) > 0, name
