@@ -166,3 +166,40 @@ def test_meta_dict_completes_lazy_entries_on_read():
     m2._thunks["x"] = lambda: 5
     assert dict(m2.items()) == {"isect_ids": 1, "x": 5} and fs.calls == 2
     assert m2.copy() == {"isect_ids": 1, "x": 5}
+
+
+def test_entry_points_reject_bad_arguments_before_any_launch():
+    """Argument validation happens on the host, ahead of any HIP call, so it can be exercised without a device:
+    every entry point answers malformed sizes with GS_ERR_INVALID_ARG / GS_ERR_UNSUPPORTED / GS_ERR_WORKSPACE (and
+    `gs_error_string` names the code) instead of launching."""
+    from gsplat import _backend as B
+
+    L = B.lib()
+    INVALID, UNSUPPORTED, WORKSPACE = -1, -2, -3
+    P = 0x1000  # a non-null, 16-byte aligned dummy: never dereferenced on these paths
+    assert L.gs_sh_fwd(10, 16, 5, P, P, None, P, None) == INVALID                 # degree > 4
+    assert L.gs_sh_fwd(10, 4, 3, P, P, None, P, None) == INVALID                  # (3+1)^2 > K
+    assert L.gs_sh_bwd(-1, 16, 3, P, P, None, P, P, None, None) == INVALID
+    assert L.gs_activate_fwd(10, 3, 3, P, P, P, P, P, None, P, 0, P, P, P, P, P, P, P, P, None) == INVALID  # K_rest < 15
+    assert L.gs_activate_fwd(10, 15, 3, P, P, P, P, P, None, P, 3, P, P, P, P, P, P, P, P, None) == INVALID  # scale_mode
+    assert L.gs_refine_gather_rows(10, 300, 0, P, P, None, P, P, None) == INVALID   # W > 256
+    assert L.gs_refine_plan(10, 300, P, P, P, P, P, None) == INVALID                # n_split_samples > 250
+    assert L.gs_l1_ssim_fwd(10, 64, P, P, None, None, P, 1 << 20, P, None) == UNSUPPORTED    # H <= 10
+    assert L.gs_l1_ssim_fwd(64, 64, P, P, None, None, P, 1, P, None) == WORKSPACE
+    assert L.gs_pixel_losses_fwd(0, P, None, None, None, None, 80.0, P, 1 << 20, P, None) == INVALID
+    assert L.gs_pixel_losses_fwd(100, P, None, None, None, P, 80.0, P, 1 << 20, P, None) == INVALID  # lidar without depth
+    assert L.gs_cube_texture_fwd(10, 0, 3, P, P, None, P, None) == INVALID          # R < 1
+    assert L.gs_cube_texture_bwd(10, 8, 100, P, None, P, P, None) == INVALID        # C > 64
+    assert L.gs_rigid_transform_fwd(10, 0, P, P, P, P, P, P, P, None) == INVALID    # no instances
+    assert L.gs_rigid_transform_fwd(10, 3, P, P + 4, P, P, P, P, P, None) == INVALID  # misaligned quats
+    too_many = L.gs_isect_bin_max_tiles() + 1
+    assert L.gs_isect_bin_count(1, 10, too_many, 1, P, P, 1, P, None, None, None) == UNSUPPORTED
+    assert L.gs_isect_bin_scatter_regions(1, 10, 4, 4, 1, 0, 2, P, P, P, P, P, None) == INVALID  # slices_per_group < 1
+    assert L.gs_densify_accumulate(0, 10, P, P, 16, 1.0, 1.0, 1.0, 0, P, P, P, None) == INVALID   # C < 1
+    assert L.gs_exclusive_scan_workspace_bytes(1000) > 0
+    for code, word in ((INVALID, b"invalid"), (UNSUPPORTED, b"unsupported"), (WORKSPACE, b"workspace")):
+        assert word in L.gs_error_string(code).lower()
+    # empty inputs are fine and launch nothing
+    assert L.gs_sh_fwd(0, 16, 3, None, None, None, None, None) == 0
+    assert L.gs_cube_texture_fwd(0, 8, 3, None, None, None, None, None) == 0
+    assert L.gs_rigid_transform_fwd(0, 0, None, None, None, None, None, None, None, None) == 0
