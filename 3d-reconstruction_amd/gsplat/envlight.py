@@ -31,6 +31,7 @@ class _CubeTexture(torch.autograd.Function):
             B.check(B.lib().gs_cube_texture_fwd(n, R, C, B.ptr(base_c), B.ptr(dirs_c), B.ptr(rot_c), B.ptr(out),
                                                 B.stream_handle(dev)), "gs_cube_texture_fwd")
         ctx.geom = (n, R, C, tuple(base.shape))
+        ctx.in_dtype = base.dtype
         ctx.has_rot = rot is not None
         ctx.save_for_backward(dirs_c, rot_c if rot_c is not None else dirs_c)
         return out.reshape(tuple(dirs.shape[:-1]) + (C,))
@@ -46,7 +47,7 @@ class _CubeTexture(torch.autograd.Function):
         with B.device_guard(dev), B.timed("gs_cube_texture_bwd", dev):
             B.check(B.lib().gs_cube_texture_bwd(n, R, C, B.ptr(dirs_c), B.ptr(rot_c), B.ptr(v), B.ptr(v_tex),
                                                 B.stream_handle(dev)), "gs_cube_texture_bwd")
-        return v_tex, None, None
+        return v_tex.to(ctx.in_dtype), None, None
 
 
 def cube_texture(base: Tensor, dirs: Tensor, rot: Optional[Tensor] = None) -> Tensor:

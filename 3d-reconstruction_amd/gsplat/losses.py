@@ -34,6 +34,7 @@ class _L1Ssim(torch.autograd.Function):
             B.check(L.gs_l1_ssim_fwd(H, W, B.ptr(pred_c), B.ptr(gt_c), B.ptr(mask_c), B.ptr(maps), B.ptr(ws), nws,
                                      B.ptr(out), B.stream_handle(dev)), "gs_l1_ssim_fwd")
         ctx.has_mask = mask is not None
+        ctx.in_dtype = pred.dtype
         if need:
             ctx.save_for_backward(pred_c, gt_c, mask_c if mask_c is not None else out, maps)
         return out
@@ -49,7 +50,7 @@ class _L1Ssim(torch.autograd.Function):
         with B.device_guard(dev), B.timed("gs_l1_ssim_bwd", dev):
             B.check(B.lib().gs_l1_ssim_bwd(H, W, B.ptr(pred), B.ptr(gt), B.ptr(mask), B.ptr(maps), B.ptr(g), B.ptr(v),
                                            B.stream_handle(dev)), "gs_l1_ssim_bwd")
-        return v, None, None, None
+        return v.to(ctx.in_dtype), None, None, None
 
 
 def l1_ssim(pred: Tensor, gt: Tensor, mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
@@ -79,6 +80,7 @@ class _PixelLosses(torch.autograd.Function):
         ctx.present = [t is not None for t in c]
         ctx.max_depth = float(max_depth)
         ctx.shapes = (tuple(opacity.shape), tuple(depth.shape) if depth is not None else None)
+        ctx.dtypes = (opacity.dtype, depth.dtype if depth is not None else None)
         ctx.save_for_backward(out, *[t for t in c if t is not None])
         return out
 
@@ -97,7 +99,8 @@ class _PixelLosses(torch.autograd.Function):
             B.check(B.lib().gs_pixel_losses_bwd(n, B.ptr(c[0]), B.ptr(c[1]), B.ptr(c[2]), B.ptr(c[3]), B.ptr(c[4]),
                                                 ctx.max_depth, B.ptr(out), B.ptr(g), B.ptr(v_op), B.ptr(v_dp),
                                                 B.stream_handle(dev)), "gs_pixel_losses_bwd")
-        return (v_op.reshape(ctx.shapes[0]), v_dp.reshape(ctx.shapes[1]) if need_depth else None, None, None, None, None)
+        return (v_op.reshape(ctx.shapes[0]).to(ctx.dtypes[0]),
+                v_dp.reshape(ctx.shapes[1]).to(ctx.dtypes[1]) if need_depth else None, None, None, None, None)
 
 
 def pixel_losses(opacity: Tensor, depth: Optional[Tensor] = None, sky_mask: Optional[Tensor] = None,

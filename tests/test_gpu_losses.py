@@ -117,3 +117,23 @@ def test_pixel_losses_match_reference_lines(gpu_device, H, W):
     assert set(only) == {"opacity_entropy"}
     none_hit = pixel_losses(opacity.to(dev), depth.to(dev), None, None, torch.zeros(H, W, device=dev))
     assert torch.isnan(none_hit["depth_l1"])
+
+
+def test_losses_accept_other_float_dtypes(gpu_device):
+    """Inputs are computed in fp32 whatever they arrive as; gradients come back in the input's dtype."""
+    from gsplat.envlight import cube_texture
+    from gsplat.losses import l1_ssim, pixel_losses
+
+    dev = gpu_device
+    pred, gt, mask = _images(40, 50, 3)
+    p64 = pred.double().to(dev).requires_grad_(True)
+    l1, ss = l1_ssim(p64, gt.to(dev), mask.to(dev))
+    (l1 + ss).backward()
+    assert p64.grad.dtype == torch.float64 and torch.isfinite(p64.grad).all()
+    op = torch.rand(40, 50, 1, dtype=torch.float64, device=dev).requires_grad_(True)
+    res = pixel_losses(op, None, (torch.rand(40, 50, device=dev) > 0.5).float())
+    (res["sky_bce"] + res["opacity_entropy"]).backward()
+    assert op.grad.dtype == torch.float64 and op.grad.shape == op.shape
+    tex = torch.rand(6, 8, 8, 3, dtype=torch.float64, device=dev).requires_grad_(True)
+    cube_texture(tex, torch.randn(100, 3, device=dev)).sum().backward()
+    assert tex.grad.dtype == torch.float64
