@@ -56,10 +56,15 @@ class FiniteFlag:
     def __init__(self, device: torch.device):
         self.word = torch.zeros(1, dtype=torch.int32, device=device)
 
+    def reset(self) -> None:
+        """Clear the collected bits (stream-ordered: calls already queued still report into the old state)."""
+        self.word.zero_()
+
     def check(self, step: Optional[int] = None) -> None:
         w = int(self.word.item()) & 0xFFFFFFFF
         if w == 0:
             return
+        self.word.zero_()  # a reported problem is reported once
         for k, name in enumerate(_KEYS):  # the reference checks key by key, NaN before Inf
             for bit, what in ((2 * k, "NaN"), (2 * k + 1, "Inf")):
                 if w >> bit & 1:
