@@ -498,22 +498,9 @@ class _RasterizeSplats(torch.autograd.Function):
         if work is not None:
             # (a tensor of its own: `order` and its size classes still describe the sort launches of `fs`)
             order_bwd = torch.empty_like(order)
-            if ctx.v_splats is not None:
-                # only the backward reads it: off the main stream, behind whatever the caller queues next (the loss)
-                main, side = torch.cuda.current_stream(dev), B.side_stream(dev)
-                side.wait_stream(main)
-                with torch.cuda.stream(side), B.device_guard(dev):
-                    B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, B.ptr(work),
-                                                         B.ptr(order_bwd), None, B.stream_handle(dev)),
-                            "gs_raster_tile_order")
-                    ctx.v_ready = torch.cuda.Event()
-                    ctx.v_ready.record(side)  # (after the fill queued on the same stream: one event covers both)
-                work.record_stream(side)
-            else:
-                with B.device_guard(dev), B.timed("gs_raster_tile_order", dev):
-                    B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, B.ptr(work),
-                                                         B.ptr(order_bwd), None, B.stream_handle(dev)),
-                            "gs_raster_tile_order")
+            with B.device_guard(dev), B.timed("gs_raster_tile_order", dev):
+                B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, B.ptr(work), B.ptr(order_bwd),
+                                                     None, B.stream_handle(dev)), "gs_raster_tile_order")
         ctx.tile_order = order_bwd
         ctx.geom = (C, N, width, height, tile_size, channels, int(ed), bool(absgrad))
         ctx.absgrad_accumulate = getattr(_tls, "absgrad_accumulate", False)
