@@ -14,3 +14,13 @@ extern "C" const char* gs_error_string(int status) {
   if (status > 0) return hipGetErrorString((hipError_t)status);
   return "gsplat_mi355x: unknown error";
 }
+
+// Zero `bytes` bytes at `ptr` on `stream` (hipMemsetAsync).  The gradient record the rasterizer's backward accumulates
+// into is cleared with this on a side stream while the forward runs; going through the raw stream handle spares the
+// host the torch stream-context switch a `tensor.zero_()` on another stream needs.
+extern "C" int gs_fill_zero(void* ptr, int64_t bytes, void* stream) {
+  if (bytes < 0 || (bytes > 0 && !ptr)) return GS_ERR_INVALID_ARG;
+  if (bytes == 0) return GS_OK;
+  const hipError_t e = hipMemsetAsync(ptr, 0, (size_t)bytes, (hipStream_t)stream);
+  return e == hipSuccess ? GS_OK : (int)e;
+}

@@ -39,6 +39,7 @@ _P = c_void_p
 _SIGNATURES = {
     "gs_version": (ctypes.c_int, []),
     "gs_error_string": (c_char_p, [ctypes.c_int]),
+    "gs_fill_zero": (ctypes.c_int, [_P, c_int64, _P]),
     "gs_projection_fwd": (ctypes.c_int, [POINTER(ProjParams)] + [_P] * 13 + [_P]),
     "gs_projection_bwd": (ctypes.c_int, [POINTER(ProjParams)] + [_P] * 11 + [c_int64] + [_P] * 10 + [_P]),
     "gs_sh_fwd": (ctypes.c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
@@ -200,6 +201,11 @@ def profiling_start(only=None) -> None:
     global _prof, _prof_only
     _prof = {}
     _prof_only = set(only) if only is not None else None
+
+
+def profiling_active() -> bool:
+    """True while per-entry-point timing is on (launches then stay on the current stream so the brackets see them)."""
+    return _prof is not None
 
 
 def profiling_stop():

@@ -474,10 +474,11 @@ class _RasterizeSplats(torch.autograd.Function):
             main, side = torch.cuda.current_stream(dev), B.side_stream(dev)
             ctx.v_splats = torch.empty_like(splats)
             side.wait_stream(main)
-            with torch.cuda.stream(side):
-                ctx.v_splats.zero_()
-                ctx.v_ready = torch.cuda.Event()
-                ctx.v_ready.record(side)
+            with B.device_guard(dev):  # (raw stream handle: no torch stream-context switch on the host)
+                B.check(B.lib().gs_fill_zero(B.ptr(ctx.v_splats), ctx.v_splats.numel() * 4, side.cuda_stream),
+                        "gs_fill_zero")
+            ctx.v_ready = torch.cuda.Event()
+            ctx.v_ready.record(side)
         # longest-first tile schedule: by list length now, by the walked length (written by the forward) for backward
         n_tiles = C * TH * TW
         work = None
@@ -498,9 +499,23 @@ class _RasterizeSplats(torch.autograd.Function):
         if work is not None:
             # (a tensor of its own: `order` and its size classes still describe the sort launches of `fs`)
             order_bwd = torch.empty_like(order)
-            with B.device_guard(dev), B.timed("gs_raster_tile_order", dev):
-                B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, B.ptr(work), B.ptr(order_bwd),
-                                                     None, B.stream_handle(dev)), "gs_raster_tile_order")
+            if ctx.v_ready is not None and not B.profiling_active():
+                # only the backward reads it: on the side stream (raw handle), behind the fill and off the main stream,
+                # where it overlaps whatever the caller queues next; one event covers the fill and the order
+                side = B.side_stream(dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with B.device_guard(dev):
+                    B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, B.ptr(work),
+                                                         B.ptr(order_bwd), None, side.cuda_stream),
+                            "gs_raster_tile_order")
+                ctx.v_ready = torch.cuda.Event()
+                ctx.v_ready.record(side)
+                work.record_stream(side)
+            else:
+                with B.device_guard(dev), B.timed("gs_raster_tile_order", dev):
+                    B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, B.ptr(work),
+                                                         B.ptr(order_bwd), None, B.stream_handle(dev)),
+                            "gs_raster_tile_order")
         ctx.tile_order = order_bwd
         ctx.geom = (C, N, width, height, tile_size, channels, int(ed), bool(absgrad))
         ctx.absgrad_accumulate = getattr(_tls, "absgrad_accumulate", False)

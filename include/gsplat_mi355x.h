@@ -72,6 +72,8 @@ typedef struct gs_proj_params {
 
 int gs_version(void);
 const char* gs_error_string(int status);
+/* hipMemsetAsync(ptr, 0, bytes) on `stream`: clears the gradient record gs_rasterize_bwd accumulates into. */
+int gs_fill_zero(void* ptr, int64_t bytes, void* stream);
 
 /* ---- fully_fused_projection (+SH, +opacity*comp, +tile count) ------------------------------- */
 int gs_projection_fwd(const gs_proj_params* p,
