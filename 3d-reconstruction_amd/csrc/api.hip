@@ -18,6 +18,8 @@ extern "C" const char* gs_error_string(int status) {
 // Zero `bytes` bytes at `ptr` on `stream` (hipMemsetAsync).  The gradient record the rasterizer's backward accumulates
 // into is cleared with this on a side stream while the forward runs; going through the raw stream handle spares the
 // host the torch stream-context switch a `tensor.zero_()` on another stream needs.
+// (A dedicated 16-B-store fill kernel clears the 320 MB record of configs[1] in 42 us against the runtime's 98 us, but
+// takes more of the part away from the forward rasterizer it overlaps: 1.268-1.273 vs 1.262-1.264 ms per step.)
 extern "C" int gs_fill_zero(void* ptr, int64_t bytes, void* stream) {
   if (bytes < 0 || (bytes > 0 && !ptr)) return GS_ERR_INVALID_ARG;
   if (bytes == 0) return GS_OK;
