@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
     float* __restrict__ out_c, float* __restrict__ out_a, int32_t* __restrict__ last_ids,
     const int32_t* __restrict__ tile_order, int32_t* __restrict__ tile_work,
     const int32_t* __restrict__ sorted_cnt, int32_t* __restrict__ redo_flags, int redo_pass,
-    const float* __restrict__ opac_override, int n_per_cam) {
+    const float* __restrict__ opac_override, int n_per_cam, float* __restrict__ out_T) {
   __shared__ float4 sg[Q_SLOTS * 3];
   __shared__ unsigned short qidx[4 * Q_STRIDE];
   const unsigned n_tiles = (unsigned)(C * TW * TH);
@@ -280,6 +280,7 @@ __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
     const float Tf = fabsf(T[p]);
     const float alpha_out = 1.f - Tf;
     out_a[pix] = alpha_out;
+    if (out_T) out_T[pix] = Tf;  // the backward's starting point, exact (1 - alpha_out has lost Tf's low bits)
     last_ids[pix] = cur[p];
 #pragma unroll
     for (int k = 0; k < CH; ++k) {
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(64) void rasterize_bwd_kernel(
     const int32_t* __restrict__ flatten_ids, int64_t n_isects, const float* __restrict__ backgrounds, int ed,
     const float* __restrict__ out_c, const float* __restrict__ out_a, const int32_t* __restrict__ last_ids,
     const float* __restrict__ v_out_c, const float* __restrict__ v_out_a, float* __restrict__ v_splats,
-    const int32_t* __restrict__ tile_order) {
+    const int32_t* __restrict__ tile_order, const float* __restrict__ final_T) {
   __shared__ float4 sg[64 * 3];
   const unsigned n_tiles = (unsigned)(C * TW * TH);
   unsigned tile;
@@ -397,7 +398,10 @@ __global__ __launch_bounds__(64) void rasterize_bwd_kernel(
     if ((x < W) && (y < H)) {
       const int64_t pix = ((int64_t)tg.cam * H + y) * W + x;
       const float Aout = out_a[pix];
-      const float Tf = 1.f - Aout;
+      // gsplat recovers T_final as 1 - render_alphas, which in fp32 carries an absolute error of half an ulp of
+      // alpha ~ 3e-8, i.e. a RELATIVE error of up to 3e-4 on the T_final ~ 1e-4 of a saturated pixel, and every
+      // gradient term of that pixel scales with it.  The forward's own T_final removes that term.
+      const float Tf = final_T ? final_T[pix] : 1.f - Aout;
       float va = v_out_a[pix];
 #pragma unroll
       for (int k = 0; k < CH; ++k) vo[p][k] = v_out_c[pix * CH + k];
@@ -605,7 +609,7 @@ static int raster_check(int32_t C, int32_t width, int32_t height, int32_t tile_s
   return GS_OK;
 }
 
-#define GS_RF_ARGS C, width, height, TW, TH, splats, isect_offsets, flatten_ids, n_isects, backgrounds, ed_last_channel, render_colors, render_alphas, last_ids, tile_order, tile_work, sorted_counts, redo_flags, redo_pass, opacity_override, n_per_camera
+#define GS_RF_ARGS C, width, height, TW, TH, splats, isect_offsets, flatten_ids, n_isects, backgrounds, ed_last_channel, render_colors, render_alphas, last_ids, tile_order, tile_work, sorted_counts, redo_flags, redo_pass, opacity_override, n_per_camera, final_T
 #define GS_RF_LAUNCH(CHN) hipLaunchKernelGGL((gs::rasterize_fwd_kernel<CHN>), grid, block, 0, s, GS_RF_ARGS)
 
 extern "C" int gs_rasterize_fwd(int32_t C, int32_t width, int32_t height, int32_t tile_size, int32_t channels,
@@ -614,7 +618,7 @@ extern "C" int gs_rasterize_fwd(int32_t C, int32_t width, int32_t height, int32_
                                 float* render_colors, float* render_alphas, int32_t* last_ids,
                                 const int32_t* tile_order, int32_t* tile_work, const int32_t* sorted_counts,
                                 int32_t* redo_flags, int32_t redo_pass, const float* opacity_override,
-                                int32_t n_per_camera, void* stream) {
+                                int32_t n_per_camera, float* final_T, void* stream) {
   int st = raster_check(C, width, height, tile_size, channels, n_isects);
   if (st != GS_OK) return st;
   if (!isect_offsets || !render_colors || !render_alphas || !last_ids) return GS_ERR_INVALID_ARG;
@@ -634,7 +638,7 @@ extern "C" int gs_rasterize_fwd(int32_t C, int32_t width, int32_t height, int32_
   return GS_OK;
 }
 
-#define GS_RB_ARGS C, width, height, TW, TH, splats, isect_offsets, flatten_ids, n_isects, backgrounds, ed_last_channel, render_colors, render_alphas, last_ids, v_render_colors, v_render_alphas, v_splats, tile_order
+#define GS_RB_ARGS C, width, height, TW, TH, splats, isect_offsets, flatten_ids, n_isects, backgrounds, ed_last_channel, render_colors, render_alphas, last_ids, v_render_colors, v_render_alphas, v_splats, tile_order, final_T
 #define GS_RB_LAUNCH(CHN)                                                                              \
   do {                                                                                                 \
     if (absgrad)                                                                                       \
@@ -648,7 +652,7 @@ extern "C" int gs_rasterize_bwd(int32_t C, int32_t width, int32_t height, int32_
                                 int64_t n_isects, const float* backgrounds, int32_t ed_last_channel,
                                 const float* render_colors, const float* render_alphas, const int32_t* last_ids,
                                 const float* v_render_colors, const float* v_render_alphas, int32_t absgrad,
-                                float* v_splats, const int32_t* tile_order, void* stream) {
+                                float* v_splats, const int32_t* tile_order, const float* final_T, void* stream) {
   int st = raster_check(C, width, height, tile_size, channels, n_isects);
   if (st != GS_OK) return st;
   if (n_isects == 0) return GS_OK;

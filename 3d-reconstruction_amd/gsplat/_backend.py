@@ -61,8 +61,8 @@ _SIGNATURES = {
     "gs_isect_offset_encode": (ctypes.c_int, [c_int64, _P, c_int32, c_int32, c_int32, _P, _P]),
     "gs_isect_tile_sort_front": (ctypes.c_int, [c_int32, c_int32, c_int32, _P, c_int64, _P, _P, c_int32, _P, _P, _P, _P, _P]),
     "gs_isect_tile_sort_redo": (ctypes.c_int, [c_int32, c_int32, c_int32, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "gs_rasterize_fwd": (ctypes.c_int, [c_int32] * 5 + [_P, _P, _P, c_int64, _P, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32, _P]),
-    "gs_rasterize_bwd": (ctypes.c_int, [c_int32] * 5 + [_P, _P, _P, c_int64, _P, c_int32, _P, _P, _P, _P, _P, c_int32, _P, _P, _P]),
+    "gs_rasterize_fwd": (ctypes.c_int, [c_int32] * 5 + [_P, _P, _P, c_int64, _P, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32, _P, _P]),
+    "gs_rasterize_bwd": (ctypes.c_int, [c_int32] * 5 + [_P, _P, _P, c_int64, _P, c_int32, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P]),
     "gs_raster_tile_order": (ctypes.c_int, [c_int32, _P, c_int64, _P, _P, _P, _P]),
     "gs_densify_accumulate": (ctypes.c_int, [c_int32, c_int32, _P, _P, c_int64, c_float, c_float, c_float, c_int32,
                                              _P, _P, _P, _P]),
@@ -203,9 +203,12 @@ def profiling_start(only=None) -> None:
     _prof_only = set(only) if only is not None else None
 
 
-def profiling_active() -> bool:
-    """True while per-entry-point timing is on (launches then stay on the current stream so the brackets see them)."""
-    return _prof is not None
+def profiling_active(label: Optional[str] = None) -> bool:
+    """True while launches labelled `label` are being bracketed (such a launch must stay on the current stream so the
+    brackets see it; every other launch keeps its production stream).  Without a label: any timing on at all."""
+    if _prof is None:
+        return False
+    return label is None or _prof_only is None or label in _prof_only
 
 
 def profiling_stop():

@@ -395,7 +395,8 @@ def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile
 
 
 # ----------------------------------------------------------------------------- rasterize
-def launch_raster_fwd(splats, offsets, flatten_ids, order, fs, bg, geom, rc, ra, last_ids, work, opac_override) -> None:
+def launch_raster_fwd(splats, offsets, flatten_ids, order, fs, bg, geom, rc, ra, last_ids, work, opac_override,
+                      final_T=None) -> None:
     """gs_rasterize_fwd (+ the redo pass of front-sorted lists) into preallocated outputs."""
     C, N, width, height, tile_size, channels, ed = geom
     dev = splats.device
@@ -410,7 +411,8 @@ def launch_raster_fwd(splats, offsets, flatten_ids, order, fs, bg, geom, rc, ra,
                                              B.ptr(last_ids), B.ptr(order), B.ptr(work),
                                              B.ptr(fs.sorted_counts) if fs is not None else None,
                                              B.ptr(fs.redo_flags) if fs is not None else None, redo_pass,
-                                             B.ptr(opac_override), N, B.stream_handle(dev)), "gs_rasterize_fwd")
+                                             B.ptr(opac_override), N, B.ptr(final_T), B.stream_handle(dev)),
+                    "gs_rasterize_fwd")
 
     raster(0)
     if fs is not None:
@@ -479,6 +481,9 @@ class _RasterizeSplats(torch.autograd.Function):
                         "gs_fill_zero")
             ctx.v_ready = torch.cuda.Event()
             ctx.v_ready.record(side)
+            # written on the side stream: if the graph is dropped without a backward, the allocator must not hand
+            # the block to a main-stream tensor while the fill is still pending
+            ctx.v_splats.record_stream(side)
         # longest-first tile schedule: by list length now, by the walked length (written by the forward) for backward
         n_tiles = C * TH * TW
         work = None
@@ -491,15 +496,17 @@ class _RasterizeSplats(torch.autograd.Function):
             with B.device_guard(dev), B.timed("gs_raster_tile_order", dev):
                 B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, None, B.ptr(order), None,
                                                      B.stream_handle(dev)), "gs_raster_tile_order")
+        # the backward starts from each pixel's final transmittance: kept exactly, not re-derived from 1 - alpha
+        final_T = torch.empty(C, height, width, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         launch_raster_fwd(splats, offsets, flatten_ids, order, fs, bg, (C, N, width, height, tile_size, channels, ed),
-                          rc, ra, last_ids, work, None)
+                          rc, ra, last_ids, work, None, final_T)
         _tls.front_sort = fs
         _tls.raster_state = (splats, offsets, isect_ids, flatten_ids, order, fs)  # handed to rasterization() for the lazy completion of meta["isect_ids"/"flatten_ids"]
         order_bwd = None
         if work is not None:
             # (a tensor of its own: `order` and its size classes still describe the sort launches of `fs`)
             order_bwd = torch.empty_like(order)
-            if ctx.v_ready is not None and not B.profiling_active():
+            if ctx.v_ready is not None and not B.profiling_active("gs_raster_tile_order"):
                 # only the backward reads it: on the side stream (raw handle), behind the fill and off the main stream,
                 # where it overlaps whatever the caller queues next; one event covers the fill and the order
                 side = B.side_stream(dev)
@@ -511,6 +518,7 @@ class _RasterizeSplats(torch.autograd.Function):
                 ctx.v_ready = torch.cuda.Event()
                 ctx.v_ready.record(side)
                 work.record_stream(side)
+                order_bwd.record_stream(side)
             else:
                 with B.device_guard(dev), B.timed("gs_raster_tile_order", dev):
                     B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, B.ptr(work),
@@ -522,15 +530,18 @@ class _RasterizeSplats(torch.autograd.Function):
         ctx.has_bg = bg is not None
         ctx.has_packed = packed_index is not None
         empty = torch.empty(0, device=dev)
+        ctx.has_final_T = final_T is not None
         ctx.save_for_backward(splats, means2d, offsets, flatten_ids, bg if bg is not None else empty, rc, ra, last_ids,
-                              packed_index if packed_index is not None else empty)
+                              packed_index if packed_index is not None else empty,
+                              final_T if final_T is not None else empty)
         ctx.mark_non_differentiable(isect_ids, flatten_ids, offsets, last_ids)
         ctx.set_materialize_grads(False)  # no zero tensors for the integer outputs' (undefined) gradients
         return rc, ra, isect_ids, flatten_ids, offsets, last_ids
 
     @staticmethod
     def backward(ctx, v_rc, v_ra, *_):
-        splats, means2d, offsets, flatten_ids, bg, rc, ra, last_ids, packed_index = ctx.saved_tensors
+        splats, means2d, offsets, flatten_ids, bg, rc, ra, last_ids, packed_index, final_T = ctx.saved_tensors
+        final_T = final_T if ctx.has_final_T else None
         C, N, width, height, tile_size, channels, ed, absgrad = ctx.geom
         dev = splats.device
         bg = bg if ctx.has_bg else None
@@ -545,8 +556,8 @@ class _RasterizeSplats(torch.autograd.Function):
             B.check(B.lib().gs_rasterize_bwd(C, width, height, tile_size, channels, B.ptr(splats), B.ptr(offsets),
                                              B.ptr(flatten_ids), flatten_ids.numel(), B.ptr(bg), ed, B.ptr(rc),
                                              B.ptr(ra), B.ptr(last_ids), B.ptr(v_rc), B.ptr(v_ra), int(absgrad),
-                                             B.ptr(v_splats), B.ptr(ctx.tile_order), B.stream_handle(dev)),
-                    "gs_rasterize_bwd")
+                                             B.ptr(v_splats), B.ptr(ctx.tile_order), B.ptr(final_T),
+                                             B.stream_handle(dev)), "gs_rasterize_bwd")
         if ctx.has_packed:
             flat = v_splats.reshape(-1, B.GS_REC)
             v_means2d = flat[packed_index, 0:2]

@@ -38,6 +38,7 @@ def all_reduce_gradients(params: Iterable[Tensor], group=None, average: bool = F
     which is the regime where RCCL's ring over the xGMI links is bandwidth- rather than latency-bound, and it avoids the
     flatten/unflatten copies of a bucketed reducer.  Ranks whose cameras saw no Gaussian still contribute zeros, so a
     missing .grad is materialised as zeros to keep the collective sequence identical on every rank."""
+    params = list(params)  # (a generator, e.g. model.parameters(), is walked twice below)
     rank, ws = world(group)
     if ws == 1:
         return

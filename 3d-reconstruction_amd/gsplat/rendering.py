@@ -80,7 +80,12 @@ class _Meta(dict):
 # no_grad the last call's splat records and sorted lists are kept and a call that differs only in `opacities` (and
 # `backgrounds`) goes straight to the rasterizer, which takes the new opacities as an override.  Results are bit-identical
 # to an independent call (same kernels, same lists).  Keyed on the identity + in-place version of the Gaussian tensors
-# and on the values of viewmats / Ks (the reference inverts camtoworlds afresh on every call).
+# and on the values of viewmats / Ks (the reference inverts camtoworlds afresh on every call).  The camera values are
+# compared on the device, and only when everything else already matches: a miss costs no host synchronisation, a hit
+# one 0-d read in exchange for the projection + intersection + sort it skips.
+# Staleness is detected through `tensor._version`, which in-place ops bump but `param.data.copy_()` / `set_()` do not:
+# after such surgery on the Gaussian tensors call `clear_cache()` (the reference's densification re-creates its
+# Parameters, /root/reference/3D-Reconstruction-main/models/gaussians/vanilla.py:285-357, which changes the identity).
 EVAL_CACHE = True
 _cache = threading.local()
 
@@ -102,11 +107,17 @@ def clear_cache() -> None:
     _cache.entry = None
 
 
-def _cache_key(gaussian_tensors, viewmats, Ks, scalars):
+def _cache_key(gaussian_tensors, scalars):
     tens = tuple(None if t is None else (t.data_ptr(), t._version, tuple(t.shape), t.dtype, str(t.device))
                  for t in gaussian_tensors)
-    cams = torch.cat([viewmats.detach().reshape(-1).float(), Ks.detach().reshape(-1).float()]).cpu().numpy().tobytes()
-    return tens + (cams,) + scalars
+    return tens + scalars
+
+
+def _same_cameras(ent, viewmats: Tensor, Ks: Tensor) -> bool:
+    vm, K = ent["viewmats"], ent["Ks"]
+    if vm.shape != viewmats.shape or K.shape != Ks.shape or vm.device != viewmats.device:
+        return False
+    return bool(((vm == viewmats.detach()).all() & (K == Ks.detach()).all()).item())
 
 
 def _as_int(v) -> int:
@@ -229,11 +240,11 @@ def rasterization(
     if needs_grad:
         _cache.entry = None  # a training step: do not keep the last eval image's records alive
     elif use_cache:
-        key = _cache_key((means, quats, scales, colors, covars), viewmats, Ks,
+        key = _cache_key((means, quats, scales, colors, covars),
                          (geom, float(near_plane), float(far_plane), float(radius_clip), float(eps2d), sh_degree,
                           render_mode, rasterize_mode))
         ent = getattr(_cache, "entry", None)
-        if ent is not None and ent["key"] == key:
+        if ent is not None and ent["key"] == key and _same_cameras(ent, viewmats, Ks):
             rc, ra, last_ids = W.rerender(ent["state"], opacities, bg, geom)
             meta = _Meta(ent["meta"])
             meta["last_ids"] = last_ids
@@ -302,6 +313,7 @@ def rasterization(
     if use_cache and state is not None:
         # a plain-dict snapshot of the call-independent entries (reading dict.items of the base class: no completion)
         _cache.entry = {"key": key, "state": state, "pins": (means, quats, scales, colors, covars),
+                        "viewmats": viewmats.detach().clone(), "Ks": Ks.detach().clone(),
                         "meta": {k: v for k, v in dict.items(meta) if k not in ("last_ids", "opacities")}}
     return render_colors, render_alphas, meta
 

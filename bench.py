@@ -6,10 +6,15 @@ Workload (BASELINE.json configs[1], SURVEY.md section 8(d) "Config 2"): 1,000,00
 tile intersection + sort + offsets + rasterize forward, a fixed random linear loss over colours and alphas, and the
 full backward to means / quats / scales / opacities / SH coefficients.  Synthetic scene (synth_scene.py, seed 42).
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one rank per GPU over RCCL.  Either the caller launches the ranks (`python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment), or
+bench.py is invoked bare and starts its N ranks itself as fresh child processes -- before anything in this process
+touches the GPU -- and exits with their status.
 
 With N ranks every rank renders its own 5-camera frame of the same Gaussians (weak scaling: cameras/frames shard,
-section 8(e)) and the Gaussian-parameter gradients are SUM all-reduced over RCCL inside the timed region.
+section 8(e)) and the Gaussian-parameter gradients are exchanged inside the timed region (gsplat.distributed).
 Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -100,6 +105,40 @@ def cpu_baseline(threads: int):
     }
 
 
+def spawn_ranks(n: int) -> int:
+    """Bare `python bench.py --gpus N` (no launcher): start the N ranks as fresh child processes of this, still
+    GPU-free, process (nothing here has called into HIP: importing torch does not), one device per rank, rendezvous on
+    127.0.0.1.  Returns the exit status for the parent: 0 only if every rank succeeded."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    status = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 1
+                print(f"bench.py: rank {r} exited with status {rc}; stopping the other ranks", file=sys.stderr)
+                for o in pending:  # (the exact children started above: their collectives would wait forever)
+                    procs[o].terminate()
+        if pending:
+            time.sleep(0.05)
+    return status
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,8 +153,13 @@ def main():
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="multi-rank dry run on fewer GPUs than ranks: gloo backend, device = LOCAL_RANK %% device_count "
                          "(exercises the N > 1 code path on a one-GPU box; the number it prints is not a result)")
+    ap.add_argument("--exchange", choices=["auto", "dense"], default="auto",
+                    help="N > 1: how the parameter gradients cross ranks (gsplat.distributed.GradientExchange); "
+                         "'dense' = one SUM all-reduce per parameter tensor")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -130,7 +174,8 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus or world == 1 and args.gpus == 1, (world, args.gpus)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
     from gsplat import _backend as B
     from gsplat.distributed import all_reduce_gradients
@@ -188,19 +233,27 @@ def main():
     kern_all = B.profiling_stop()
     dom = max(kern_all, key=lambda k: kern_all[k][1] * kern_all[k][0]) if kern_all else None
 
-    # timed region: only the dominant kernel stays bracketed (two events per step on its launch stream)
+    # timed region: the production stream schedule; only the dominant kernel stays bracketed (two events per step on
+    # its launch stream), plus one event per step boundary for the median step time of SURVEY.md section 8(d)
     B.profiling_start(only=[dom] if dom else [])
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        marks[i].record()
         step()
+    marks[args.steps].record()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
     kern = B.profiling_stop()
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if step_ms else float("nan")
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        if args.rehearse_gloo:
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -234,6 +287,7 @@ def main():
         out = {
             "metric": "Mpix/s fwd+bwd, 1M Gaussians @375x1242x5 cams" if headline else "Mpix/s fwd+bwd", "value": round(value, 3), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "ms_per_step_median_hip_events": round(median_ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "gaussians": N, "cams_per_gpu": C,
                        "width": W, "height": H, "visible_pairs_V": V, "n_isects_I": I,

@@ -248,6 +248,8 @@ int gs_rasterize_fwd(int32_t C, int32_t width, int32_t height, int32_t tile_size
                                                      reference's per-class re-renders, R/models/trainers/scene_graph.py:
                                                      282-301, reuse one projection + sort and change only this) */
                      int32_t n_per_camera,        /* N: rows per camera of `splats` (used with opacity_override) */
+                     float* final_T,              /* out [C,H,W] or NULL: each pixel's final transmittance, exactly
+                                                     (render_alphas = 1 - final_T rounds its low bits away) */
                      void* stream);
 
 int gs_rasterize_bwd(int32_t C, int32_t width, int32_t height, int32_t tile_size,
@@ -262,6 +264,8 @@ int gs_rasterize_bwd(int32_t C, int32_t width, int32_t height, int32_t tile_size
                      int32_t absgrad,
                      float* v_splats,             /* in/out [*,16], PRE-ZEROED, atomically accumulated */
                      const int32_t* tile_order,   /* launch order of the tiles or NULL */
+                     const float* final_T,        /* [C,H,W] from the forward, or NULL: use 1 - render_alphas as gsplat does
+                                                     (loses up to 3e-4 relative on saturated pixels' gradients) */
                      void* stream);
 
 /* Longest-first launch order of the tiles (a permutation of 0..n_tiles-1; speed only, never results): by

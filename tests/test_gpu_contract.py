@@ -39,23 +39,41 @@ def test_pipeline_golden_fixture(gpu_device):
     assert_close("G1.depths", meta["depths"].cpu()[both], torch.from_numpy(z["meta_depths"])[both])
     assert_close("G1.conics", meta["conics"].cpu()[both], torch.from_numpy(z["meta_conics"])[both], rtol=2e-4)
     assert_close("G1.opacities", meta["opacities"].cpu()[both], torch.from_numpy(z["meta_opacities"])[both])
-    # G2 integer stages: exact whenever the (float-derived) radii agree everywhere
-    if (r_g == r_o).all():
-        assert np.array_equal(meta["tiles_per_gauss"].cpu().numpy(), z["meta_tiles_per_gauss"])
-        assert np.array_equal(meta["flatten_ids"].cpu().numpy(), z["meta_flatten_ids"])
-        assert np.array_equal(meta["isect_offsets"].cpu().numpy(), z["meta_isect_offsets"])
-        same_depth_bits = np.array_equal(meta["isect_ids"].cpu().numpy() >> 32, z["meta_isect_ids"] >> 32)
-        assert same_depth_bits  # camera|tile part of the keys (the low 32 bits are fp32 depth bits, fp64 oracle differs)
-    # G3 forward, G4 gradients (flip budget as in test_gpu_parity.py)
+    # G2 integer stages.  Rows whose (float-derived) radius or tile box differs from the fp64 fixture are counted
+    # against a 2e-3 budget; everything those rows do not touch must be bit-exact: the tile counts of every other row,
+    # and the sorted list (flatten_ids) + its length (isect_offsets) of every tile none of them lies in on either side.
+    tpg_g, tpg_o = meta["tiles_per_gauss"].cpu().numpy(), z["meta_tiles_per_gauss"]
+    dirty = (r_g != r_o) | (tpg_g != tpg_o)
+    assert dirty.mean() <= 2e-3, f"{int(dirty.sum())} rows differ in radius / tile count from the fixture"
+    assert np.array_equal(tpg_g[~dirty], tpg_o[~dirty])
+    dirty_ids = set(np.nonzero(dirty.reshape(-1))[0].tolist())
+    f_g, f_o = meta["flatten_ids"].cpu().numpy(), z["meta_flatten_ids"]
+    o_g = np.append(meta["isect_offsets"].cpu().numpy().reshape(-1), f_g.size)
+    o_o = np.append(z["meta_isect_offsets"].reshape(-1), f_o.size)
+    k_g, k_o = meta["isect_ids"].cpu().numpy() >> 32, z["meta_isect_ids"] >> 32
+    n_clean = 0
+    for t in range(o_g.size - 1):
+        lg, lo = f_g[o_g[t]:o_g[t + 1]], f_o[o_o[t]:o_o[t + 1]]
+        if dirty_ids and (dirty_ids.intersection(lg.tolist()) or dirty_ids.intersection(lo.tolist())):
+            continue
+        n_clean += 1
+        assert np.array_equal(lg, lo), f"tile {t}: sorted list differs from the fixture"
+        # camera|tile part of the keys (the low 32 bits are fp32 depth bits; the fp64 oracle's differ)
+        assert np.array_equal(k_g[o_g[t]:o_g[t + 1]], k_o[o_o[t]:o_o[t + 1]]), t
+    assert n_clean >= 0.9 * (o_g.size - 1)
+    if not dirty_ids:
+        assert np.array_equal(o_g, o_o)
+    # G3 forward (flip budget as in test_gpu_parity.py), G4 gradients: measured rel-L2 <= 1.3e-5 and nothing outside
+    # 1e-5 * max|ref| + 1e-4 |ref| (profiles/r02_parity_report.txt); asserted at ~3x as budgets
     assert_close("G3.colors", rc, torch.from_numpy(z["render_colors"]), max_bad_frac=2e-3)
     assert_close("G3.alphas", ra, torch.from_numpy(z["render_alphas"]), max_bad_frac=2e-3)
     for k in ["means", "quats", "scales", "opacities", "colors"]:
-        assert_close(f"G4.v_{k}", a[k].grad, torch.from_numpy(z[f"grad_{k}"]), rtol=1e-3, atol=1e-4,
-                     max_bad_frac=1e-2, max_rel_l2=2e-3, scale_atol=True)
-    assert_close("G4.v_viewmats", vm.grad[:, :3], torch.from_numpy(z["grad_viewmats"])[:, :3], rtol=1e-3, atol=1e-4,
-                 max_bad_frac=0.1, max_rel_l2=2e-3, scale_atol=True)
-    assert_close("G4.means2d.grad", meta["means2d"].grad, torch.from_numpy(z["grad_means2d"]), rtol=1e-3, atol=1e-4,
-                 max_bad_frac=1e-2, max_rel_l2=2e-3, scale_atol=True)
+        assert_close(f"G4.v_{k}", a[k].grad, torch.from_numpy(z[f"grad_{k}"]), max_bad_frac=1.5e-3, max_rel_l2=5e-5,
+                     scale_atol=True)
+    assert_close("G4.v_viewmats", vm.grad[:, :3], torch.from_numpy(z["grad_viewmats"])[:, :3], max_bad_frac=2.0 / 24.0,
+                 max_rel_l2=5e-5, scale_atol=True)
+    assert_close("G4.means2d.grad", meta["means2d"].grad, torch.from_numpy(z["grad_means2d"]), max_bad_frac=1.5e-3,
+                 max_rel_l2=5e-5, scale_atol=True)
 
 
 def test_sh_golden_fixture(gpu_device):

@@ -1,6 +1,8 @@
 """Eval re-render cache (gsplat.rendering.EVAL_CACHE): the reference renders one image up to six times under no_grad with
 only the opacities masked per class (/root/reference/3D-Reconstruction-main/models/trainers/scene_graph.py:282-301).
 A cached re-render must be bit-identical to an independent call, and anything else that changes must miss."""
+import math
+
 import pytest
 import torch
 
@@ -113,3 +115,61 @@ def test_cache_misses_when_inputs_change(gpu_device):
     assert R._cache.entry is None
     (rc.sum() + ra.sum()).backward()
     assert q["means"].grad is not None and torch.isfinite(q["means"].grad).all()
+
+
+def test_data_surgery_needs_clear_cache_and_inplace_ops_miss(gpu_device):
+    """The key tracks `tensor._version`: an in-place op on a Gaussian tensor misses by itself; `.data` surgery does
+    not bump the version, so the documented contract is `clear_cache()` after it."""
+    import synth_scene
+    from gsplat import rendering as R
+
+    dev = gpu_device
+    N, C, W, H = 3000, 1, 120, 80
+    g = synth_scene.make_gaussians(N, sh_degree=None, extent=8.0)
+    gg = {k: v.to(dev) for k, v in g.items()}
+    vm, Ks = synth_scene.make_cameras(C, W, H)
+    vm, Ks = vm.to(dev), Ks.to(dev)
+
+    def render():
+        with torch.no_grad():
+            return R.rasterization(gg["means"], gg["quats"], gg["scales"], gg["opacities"], gg["colors"], vm, Ks, W, H,
+                                   packed=False, render_mode="RGB+ED")
+
+    R.clear_cache()
+    a = render()
+    e0 = R._cache.entry
+    gg["means"].add_(0.05)  # in-place: version bump -> miss
+    b = render()
+    assert R._cache.entry is not e0
+    assert not torch.equal(a[0], b[0])
+    gg["means"].data.add_(0.05)  # .data surgery: the caller clears the cache
+    R.clear_cache()
+    c = render()
+    with R.no_eval_cache():
+        ref = render()
+    assert torch.equal(c[0], ref[0]) and torch.equal(c[1], ref[1])
+    R.clear_cache()
+
+
+def test_forward_dropped_without_backward_leaves_other_tensors_alone(gpu_device):
+    """The gradient record and the backward tile order are written on the side stream.  If the autograd graph is freed
+    without a backward, the allocator must not hand their blocks to a main-stream tensor while those writes are still
+    pending (record_stream in _RasterizeSplats.forward)."""
+    import synth_scene
+    from gsplat import rendering as R
+
+    dev = gpu_device
+    N, C, W, H = 200_000, 2, 400, 300
+    g = synth_scene.make_gaussians(N, sh_degree=None, extent=20.0)
+    gg = {k: v.to(dev).requires_grad_(True) for k, v in g.items()}
+    vm, Ks = synth_scene.make_cameras(C, W, H)
+    vm, Ks = vm.to(dev), Ks.to(dev)
+    for _ in range(5):
+        rc, ra, meta = R.rasterization(gg["means"], gg["quats"], gg["scales"], gg["opacities"], gg["colors"], vm, Ks,
+                                       W, H, packed=False, render_mode="RGB+ED", absgrad=True)
+        del rc, ra, meta  # no backward: the graph (and the zero-filled gradient record) is dropped here
+        ones = torch.ones(C, N, 16, device=dev)  # the record's size: the block the allocator would reuse
+        small = torch.ones(C * math.ceil(W / 16) * math.ceil(H / 16), device=dev, dtype=torch.int32)
+        torch.cuda.synchronize()
+        assert bool((ones == 1).all()) and bool((small == 1).all())
+        del ones, small

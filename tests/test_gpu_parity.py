@@ -354,16 +354,21 @@ def test_end_to_end_fwd_bwd(gpu_device, mode, sh):
     # or drops a tile for that Gaussian, changing a few pixels by <= ~1e-2.  Budget: 0.2 % of pixels.
     assert_close(f"e2e.{mode}.alphas", ra, rao, max_bad_frac=2e-3)
     assert_close(f"e2e.{mode}.colors", rc, rco, max_bad_frac=2e-3)
+    # Gradients: fp32 sums of thousands of terms (and float atomics, so run-to-run order varies).  Measured
+    # (profiles/r02_parity_report.txt): rel-L2 <= 1.5e-5 for every parameter, and at the north_star's strict elementwise
+    # bar (1e-5 abs + 1e-4 rel) <= 5e-4 of the elements outside.  Asserted at ~3x the measured values, stated as budgets.
     for k in ["means", "quats", "scales", "opacities", "colors"]:
         assert torch.isfinite(gg[k].grad).all()
-        close_report(f"e2e.{mode}.v_{k}", gg[k].grad, go[k].grad)
-        frac, rel_l2, _ = close_report(f"e2e.{mode}.v_{k}(atol1e-4)", gg[k].grad, go[k].grad, atol=1e-4, rtol=1e-3)
-        assert rel_l2 <= 2e-3, (k, rel_l2)
-        assert frac <= 1e-2, (k, frac)
-    frac, rel_l2, _ = close_report(f"e2e.{mode}.v_viewmats", vmg.grad[:, :3, :], vmo.grad[:, :3, :], atol=1e-4, rtol=1e-3)
-    assert rel_l2 <= 2e-3
+        frac, rel_l2, _ = close_report(f"e2e.{mode}.v_{k}", gg[k].grad, go[k].grad)
+        assert rel_l2 <= 5e-5, (k, rel_l2)
+        assert frac <= 1.5e-3, (k, frac)
+    # v_viewmats: 12 numbers per camera, each a sum over every visible Gaussian with heavy cancellation, so the absolute
+    # term of the elementwise bar is taken relative to the largest entry (scale_atol); rel-L2 measured <= 6e-6
+    frac, rel_l2, _ = close_report(f"e2e.{mode}.v_viewmats", vmg.grad[:, :3, :], vmo.grad[:, :3, :], scale_atol=True)
+    assert rel_l2 <= 5e-5, rel_l2
+    assert frac <= 1.0 / 36.0 + 1e-9, frac
     assert meta["means2d"].grad is not None and meta["means2d"].absgrad.shape == (C, N, 2)
-    assert float(gg["opacities"].grad[:300].abs().max()) >= 0.0  # finite, may be non-zero (d/d opacity at 0)
+    assert torch.isfinite(gg["opacities"].grad[:300]).all()  # d/d opacity at exactly 0 is finite (may be non-zero)
 
 
 def test_viewer_call_and_empty(gpu_device):
