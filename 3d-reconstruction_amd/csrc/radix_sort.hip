@@ -12,6 +12,8 @@
 // LDS-atomic pile-up when a whole wave holds one digit (the (camera|tile) passes do).
 // The element count may live in device memory (`n_dev`): grids are sized for `n_max` and surplus workgroups exit,
 // which lets the host enqueue a sort whose size it does not know yet.  HBM-bound integer work.
+#include <mutex>
+
 #include "gs_common.hpp"
 
 namespace gs {
@@ -186,29 +188,18 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
 
 }  // namespace gs
 
+static int64_t rs_table_bytes(int64_t n);
+
 extern "C" int64_t gs_radix_sort_workspace_bytes(int64_t n) {
   if (n <= 0) return 256;
-  const int64_t nb = gs::ceil_div(n, gs::RS_TILE);
-  const int64_t table = ((nb * gs::RS_MAX_RADIX * (int64_t)sizeof(uint32_t) + 255) / 256) * 256;
-  return table + gs::RS_MAX_RADIX * (int64_t)sizeof(uint32_t);
+  return rs_table_bytes(n) + gs::RS_MAX_RADIX * (int64_t)sizeof(uint32_t);
 }
 
-extern "C" int gs_radix_sort_pairs_u64_u32_ex(int64_t n_max, const int64_t* n_dev, int32_t begin_bit, int32_t end_bit,
-                                              uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b,
-                                              void* workspace, int64_t workspace_bytes, int32_t* result_in_b_host,
-                                              void* stream) {
-  if (n_max < 0 || begin_bit < 0 || end_bit < begin_bit || end_bit > 64 || !result_in_b_host) return GS_ERR_INVALID_ARG;
-  *result_in_b_host = 0;
-  if (n_max == 0 || end_bit == begin_bit) return GS_OK;
-  if (n_max >= ((int64_t)1 << 31)) return GS_ERR_UNSUPPORTED;
-  if (!keys_a || !vals_a || !keys_b || !vals_b || !workspace) return GS_ERR_INVALID_ARG;
-  if (workspace_bytes < gs_radix_sort_workspace_bytes(n_max)) return GS_ERR_WORKSPACE;
-  hipStream_t s = (hipStream_t)stream;
+// The passes of one sort.  `table` holds nb * RS_MAX_RADIX counters (digit-major, row stride nb), `totals` RS_MAX_RADIX.
+static int rs_run(int64_t n_max, const int64_t* n_dev, int32_t begin_bit, int32_t end_bit, uint64_t* keys_a,
+                  uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, uint32_t* table, uint32_t* totals,
+                  int32_t* result_in_b_host, hipStream_t s) {
   const int64_t nb = gs::ceil_div(n_max, gs::RS_TILE);
-  const int64_t table_bytes = ((nb * gs::RS_MAX_RADIX * (int64_t)sizeof(uint32_t) + 255) / 256) * 256;
-  uint32_t* table = (uint32_t*)workspace;
-  uint32_t* totals = (uint32_t*)((char*)workspace + table_bytes);
-
   const int total_bits = end_bit - begin_bit;
   const int npass = (total_bits + gs::RS_MAX_BITS - 1) / gs::RS_MAX_BITS;
   const int bits_per_pass = (total_bits + npass - 1) / npass;
@@ -233,6 +224,79 @@ extern "C" int gs_radix_sort_pairs_u64_u32_ex(int64_t n_max, const int64_t* n_de
   }
   *result_in_b_host = in_b;
   return GS_OK;
+}
+
+static int64_t rs_table_bytes(int64_t n) {
+  const int64_t nb = gs::ceil_div(n, gs::RS_TILE);
+  return ((nb * gs::RS_MAX_RADIX * (int64_t)sizeof(uint32_t) + 255) / 256) * 256;
+}
+
+extern "C" int gs_radix_sort_pairs_u64_u32_ex(int64_t n_max, const int64_t* n_dev, int32_t begin_bit, int32_t end_bit,
+                                              uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b,
+                                              void* workspace, int64_t workspace_bytes, int32_t* result_in_b_host,
+                                              void* stream) {
+  if (n_max < 0 || begin_bit < 0 || end_bit < begin_bit || end_bit > 64 || !result_in_b_host) return GS_ERR_INVALID_ARG;
+  *result_in_b_host = 0;
+  if (n_max == 0 || end_bit == begin_bit) return GS_OK;
+  if (n_max >= ((int64_t)1 << 31)) return GS_ERR_UNSUPPORTED;
+  if (!keys_a || !vals_a || !keys_b || !vals_b || !workspace) return GS_ERR_INVALID_ARG;
+  if (workspace_bytes < gs_radix_sort_workspace_bytes(n_max)) return GS_ERR_WORKSPACE;
+  uint32_t* table = (uint32_t*)workspace;
+  uint32_t* totals = (uint32_t*)((char*)workspace + rs_table_bytes(n_max));
+  return rs_run(n_max, n_dev, begin_bit, end_bit, keys_a, vals_a, keys_b, vals_b, table, totals, result_in_b_host,
+                (hipStream_t)stream);
+}
+
+// ---- the same sort for callers that cannot allocate (include/gsplat_mi355x.h, gs_radix_sort_pairs_u64_u32_static) ----
+// The digit table and the digit totals live in a file-scope device array instead of a caller workspace.  Every GPU the
+// library runs on holds its own copy of the array (8 MiB + 2 KiB until the process ends) at its own address; the host
+// gets that address once per device from hipGetSymbolAddress and passes it to the kernels like any other workspace --
+// the array's NAME is a host-side stand-in and is never handed to a kernel.  Nothing in the table has to start at
+// zero: every pass's histogram kernel overwrites each counter the scan and the scatter of that pass read.
+namespace {
+constexpr int64_t RS_STATIC_MAX_N = GS_RADIX_SORT_STATIC_MAX_N;
+constexpr int64_t RS_STATIC_TABLE_BYTES = (RS_STATIC_MAX_N / gs::RS_TILE) * gs::RS_MAX_RADIX * (int64_t)sizeof(uint32_t);
+constexpr int64_t RS_STATIC_BYTES = RS_STATIC_TABLE_BYTES + gs::RS_MAX_RADIX * (int64_t)sizeof(uint32_t);
+static_assert(RS_STATIC_MAX_N % gs::RS_TILE == 0 && RS_STATIC_TABLE_BYTES % 256 == 0, "table size");
+constexpr int RS_MAX_DEVICES = 64;
+}  // namespace
+
+static __device__ __align__(256) unsigned char scratch[RS_STATIC_BYTES];
+
+static void* g_scratch_ptr[RS_MAX_DEVICES];  // per device: address of that device's copy of `scratch`
+static std::mutex g_scratch_mutex;
+
+// Address of the current device's `scratch` (looked up once per device, with that device current).
+static int rs_static_scratch(void** out) {
+  int dev = -1;
+  GS_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= RS_MAX_DEVICES) return GS_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    void* ptr = nullptr;
+    GS_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return GS_ERR_WORKSPACE;
+    g_scratch_ptr[dev] = ptr;
+  }
+  *out = g_scratch_ptr[dev];
+  return GS_OK;
+}
+
+extern "C" int gs_radix_sort_pairs_u64_u32_static(int64_t n, int32_t begin_bit, int32_t end_bit, uint64_t* keys_a,
+                                                  uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b,
+                                                  int32_t* result_in_b_host, void* stream) {
+  if (n < 0 || begin_bit < 0 || end_bit < begin_bit || end_bit > 64 || !result_in_b_host) return GS_ERR_INVALID_ARG;
+  *result_in_b_host = 0;
+  if (n > RS_STATIC_MAX_N) return GS_ERR_WORKSPACE;  // beyond the static table: use the workspace entry points
+  if (n == 0 || end_bit == begin_bit) return GS_OK;
+  if (!keys_a || !vals_a || !keys_b || !vals_b) return GS_ERR_INVALID_ARG;
+  void* ptr = nullptr;
+  const int st = rs_static_scratch(&ptr);
+  if (st != GS_OK) return st;
+  uint32_t* table = (uint32_t*)ptr;
+  uint32_t* totals = (uint32_t*)((char*)ptr + RS_STATIC_TABLE_BYTES);
+  return rs_run(n, nullptr, begin_bit, end_bit, keys_a, vals_a, keys_b, vals_b, table, totals, result_in_b_host,
+                (hipStream_t)stream);
 }
 
 extern "C" int gs_radix_sort_pairs_u64_u32_bits(int64_t n, int32_t begin_bit, int32_t end_bit, uint64_t* keys_a,

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "gs_radix_sort_pairs_u64_u32_ex": (ctypes.c_int, [c_int64, _P, c_int32, c_int32, _P, _P, _P, _P, _P, c_int64, POINTER(c_int32), _P]),
     "gs_radix_sort_pairs_u64_u32_bits": (ctypes.c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P, c_int64, POINTER(c_int32), _P]),
     "gs_radix_sort_pairs_u64_u32": (ctypes.c_int, [c_int64, c_int32, _P, _P, _P, _P, _P, c_int64, POINTER(c_int32), _P]),
+    "gs_radix_sort_pairs_u64_u32_static": (ctypes.c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, POINTER(c_int32), _P]),
     "gs_isect_offset_encode": (ctypes.c_int, [c_int64, _P, c_int32, c_int32, c_int32, _P, _P]),
     "gs_isect_tile_sort_front": (ctypes.c_int, [c_int32, c_int32, c_int32, _P, c_int64, _P, _P, c_int32, _P, _P, _P, _P, _P]),
     "gs_isect_tile_sort_redo": (ctypes.c_int, [c_int32, c_int32, c_int32, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),

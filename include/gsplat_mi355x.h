@@ -165,6 +165,20 @@ int gs_radix_sort_pairs_u64_u32_ex(int64_t n_max, const int64_t* n_dev, int32_t 
                                    void* workspace, int64_t workspace_bytes,
                                    int32_t* result_in_b_host, void* stream);
 
+/* The same sort with NO workspace argument and no allocation of any kind.  It has no counterpart in the reference (nor
+ * in gsplat, whose cub sort takes a caller-allocated temp buffer): it is for callers that cannot allocate -- code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc -- and so cannot size and provide the
+ * workspace of the entry points above.  The digit table lives in a static device array of the library
+ * (GS_RADIX_SORT_STATIC_MAX_N / 4096 * 2 KiB + 2 KiB = 8 MiB + 2 KiB per GPU the library runs on, held until the process
+ * ends); n > GS_RADIX_SORT_STATIC_MAX_N returns GS_ERR_WORKSPACE.  Same kernels, same result bit for bit as
+ * gs_radix_sort_pairs_u64_u32_bits.  All calls on one GPU share that GPU's table: calls that overlap in time on one GPU
+ * (different streams or threads) race -- serialise them. */
+#define GS_RADIX_SORT_STATIC_MAX_N (1 << 24)
+int gs_radix_sort_pairs_u64_u32_static(int64_t n, int32_t begin_bit, int32_t end_bit,
+                                       uint64_t* keys_a, uint32_t* vals_a,
+                                       uint64_t* keys_b, uint32_t* vals_b,
+                                       int32_t* result_in_b_host, void* stream);
+
 int gs_isect_offset_encode(int64_t n_isects, const int64_t* isect_ids_sorted,
                            int32_t C, int32_t tile_w, int32_t tile_h,
                            int32_t* offsets, /* out [C,tile_h,tile_w] */
