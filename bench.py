@@ -72,6 +72,25 @@ def measured_traffic(kernel, N, C, H, W):
     return int(k["hbm_bytes_per_launch"]) if k else None
 
 
+def measured_issue(kernel):
+    """The dominant kernel's secondary roofline from the committed SQ / TCC PMC passes (profiles/pmc_issue.py writes the
+    file from profiles/collect_pmc.sh's runs of this same command): the tile rasterizer is not HBM-bound by
+    construction, what bounds it is vector-ALU issue."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "issue.json")) as f:
+            k = json.load(f).get("kernels", {}).get(kernel)
+    except (OSError, ValueError):
+        return None
+    if not k or "valu_issue_frac" not in k:
+        return None
+    return {"bound": "valu_issue", "frac": k["valu_issue_frac"], "valu_active_per_simd": k["valu_active"],
+            "waves_per_simd": k.get("waves_per_simd"), "insts_valu": k.get("insts_valu"),
+            "lds_bank_conflict_rate": k.get("lds_bank_conflict_rate"), "atomic_GBps": k.get("atomic_GBps"),
+            "atomic_frac_of_peak": k.get("atomic_frac_of_1300GBps"),
+            "source": "profiles/issue.json (rocprofv3 --pmc SQ_ACTIVE_INST_VALU, SQ_BUSY_CYCLES, SQ_LDS_BANK_CONFLICT, "
+                      "TCC_EA0_ATOMIC over this command)"}
+
+
 def cpu_baseline(threads: int):
     """BASELINE.json configs[0]: the oracle (pure-PyTorch restatement of gsplat's algorithm) on host cores,
     100k Gaussians, SH degree 3, one 1242x375 camera, a few fwd+bwd steps (~12-20 s of CPU work)."""
@@ -182,6 +201,7 @@ def main():
     from gsplat.rendering import rasterization
 
     N, C, W, H, K, D = args.gaussians, args.cams, args.width, args.height, 16, 4
+    headline_shape = (N, C, W, H) == (1_000_000, 5, 1242, 375)
     g = synth_scene.make_gaussians(N, sh_degree=3, seed=42)
     params = {k: v.to(dev).requires_grad_(True) for k, v in g.items()}
     # weak scaling: rank r renders frame r of the 5-camera rig (ego advances 0.5 m per frame)
@@ -269,7 +289,8 @@ def main():
             ach = bytes_[dom] / (per_launch_ms * 1e-3) / 1e9
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": measured_traffic(dom, N, C, H, W),
-                        "algorithmic_bytes_per_launch": bytes_[dom], "avg_launch_ms": round(per_launch_ms, 4)}
+                        "algorithmic_bytes_per_launch": bytes_[dom], "avg_launch_ms": round(per_launch_ms, 4),
+                        "secondary": measured_issue(dom) if headline_shape else None}
         # the same figure for every stage that has algorithmic bytes (pre-pass launch averages; the sort chain and the
         # redo launches are folded into their stage's entry point)
         per_kernel = {}
