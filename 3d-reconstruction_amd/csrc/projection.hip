@@ -154,9 +154,11 @@ __global__ __launch_bounds__(256) void projection_fwd_kernel(
     const float* __restrict__ scales, const float* __restrict__ opacities, const float* __restrict__ viewmats,
     const float* __restrict__ Ks, const float* __restrict__ campos, const float* __restrict__ colors,
     int32_t* __restrict__ radii, float* __restrict__ means2d, float* __restrict__ splats,
-    int32_t* __restrict__ tiles_per_gauss, const float* __restrict__ covars) {
+    int32_t* __restrict__ tiles_per_gauss, const float* __restrict__ covars, uint64_t* __restrict__ vis_words,
+    int32_t* __restrict__ vis_counts) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= p.N) return;
+  const int n_words = (p.N + 63) >> 6;
   const float mu[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
   const float opac = opacities[n];
   float S[6];
@@ -193,6 +195,15 @@ __global__ __launch_bounds__(256) void projection_fwd_kernel(
         radius = ceilf(3.f * sqrtf(v1));
         ok = radius > p.radius_clip;
         ok = ok && !(pr.mx + radius <= 0.f || pr.mx - radius >= W || pr.my + radius <= 0.f || pr.my - radius >= H);
+      }
+    }
+    if (vis_words) {
+      // visibility bitmap of this wave's 64 Gaussians for camera c + its population: what the packed colour-gradient
+      // message of the backward (gs_projection_bwd_split) and its consumers index by (every live lane gets here)
+      const unsigned long long vb = __ballot(ok);
+      if ((threadIdx.x & 63) == 0) {
+        vis_words[(int64_t)c * n_words + (n >> 6)] = vb;
+        vis_counts[(int64_t)c * n_words + (n >> 6)] = __popcll(vb);
       }
     }
     if (!ok) {
@@ -253,8 +264,29 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-template <int CMODE, int DEG, bool VIEWGRAD>
-__global__ __launch_bounds__(256, 2) void projection_bwd_kernel(
+// Layout of the packed colour-gradient message (gs_colour_message_layout): byte offsets of its sections.
+struct MsgLayout {
+  int64_t campos, words, prefix, vals, total;
+};
+__host__ __device__ inline MsgLayout msg_layout(int C, int N, int64_t cap) {
+  const int64_t W = (N + 63) >> 6;
+  auto up = [](int64_t x) { return (x + 255) / 256 * 256; };
+  MsgLayout L;
+  L.campos = 16;  // behind the header {int32 n_cams, 12 B reserved}
+  L.words = up(16 + (int64_t)C * 12);
+  L.prefix = L.words + up((int64_t)C * W * 8);
+  L.vals = L.prefix + up((int64_t)C * W * 4);
+  L.total = L.vals + up(cap * 12);
+  return L;
+}
+
+// SHSPLIT (only with CMODE == GS_COLOR_SH): the SH part of the backward is NOT done here.  Instead the clamp-gated
+// colour gradient of every visible (camera, Gaussian) pair is written, packed in ascending (c, n) order, into the
+// colour-gradient message together with the visibility words, their prefix and the camera centres; sh_bwd_packed_kernel
+// turns any number of such messages (this rank's, or every rank's after an all-gather) into v_sh and the view-direction
+// part of v_means.  Without the 48 SH accumulators the kernel needs a third of the registers.
+template <int CMODE, int DEG, bool VIEWGRAD, bool SHSPLIT = false>
+__global__ __launch_bounds__(256, SHSPLIT ? 4 : 2) void projection_bwd_kernel(
     gs_proj_params p, const float* __restrict__ means, const float* __restrict__ quats,
     const float* __restrict__ scales, const float* __restrict__ opacities, const float* __restrict__ viewmats,
     const float* __restrict__ Ks, const float* __restrict__ campos, const float* __restrict__ colors,
@@ -262,8 +294,10 @@ __global__ __launch_bounds__(256, 2) void projection_bwd_kernel(
     int64_t ld_vm2, const float* __restrict__ v_splats, float* __restrict__ v_means, float* __restrict__ v_quats,
     float* __restrict__ v_scales, float* __restrict__ v_opacities, float* __restrict__ v_colors,
     float* __restrict__ v_viewmats, float* __restrict__ v_campos, const float* __restrict__ covars,
-    float* __restrict__ v_covars) {
-  constexpr int NB = (CMODE == GS_COLOR_SH) ? (DEG + 1) * (DEG + 1) : 1;
+    float* __restrict__ v_covars, const int32_t* __restrict__ vis_prefix = nullptr,
+    unsigned char* __restrict__ msg = nullptr, int64_t msg_cap = 0, int msg_cams = 0) {
+  static_assert(!SHSPLIT || CMODE == GS_COLOR_SH, "SHSPLIT is the SH colour path");
+  constexpr int NB = (CMODE == GS_COLOR_SH && !SHSPLIT) ? (DEG + 1) * (DEG + 1) : 1;
   const int n_raw = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = n_raw < p.N;
   const int n = live ? n_raw : p.N - 1;  // keep whole waves alive for the VIEWGRAD reductions
@@ -286,13 +320,40 @@ __global__ __launch_bounds__(256, 2) void projection_bwd_kernel(
   float v_mu[3] = {0.f, 0.f, 0.f};
   float v_S[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // full symmetric gradient matrix, unique entries
   float v_op = 0.f;
-  float v_col[(CMODE == GS_COLOR_SH) ? NB * 3 : 4];
+  float v_col[(CMODE == GS_COLOR_SH && !SHSPLIT) ? NB * 3 : 4];
 #pragma unroll
-  for (int k = 0; k < ((CMODE == GS_COLOR_SH) ? NB * 3 : 4); ++k) v_col[k] = 0.f;
+  for (int k = 0; k < ((CMODE == GS_COLOR_SH && !SHSPLIT) ? NB * 3 : 4); ++k) v_col[k] = 0.f;
+  const int n_words = (p.N + 63) >> 6;
+  // (the message is laid out for msg_cams >= C cameras: the largest camera count of any rank)
+  const MsgLayout ML = msg_layout(SHSPLIT ? msg_cams : p.C, p.N, msg_cap);
+  if constexpr (SHSPLIT) {
+    if (n_raw == 0) *reinterpret_cast<int32_t*>(msg) = p.C;
+  }
 
   for (int c = 0; c < p.C; ++c) {
     const int64_t idx = (int64_t)c * p.N + n;
     const bool vis = live && (radii[idx] > 0);
+    int64_t pack_row = 0;  // SHSPLIT: this pair's row of the packed values
+    if constexpr (SHSPLIT) {
+      const unsigned long long vb = __ballot(vis);
+      const int lane = threadIdx.x & 63;
+      // (n_raw: the wave's own word even where its tail lanes are clamped to N - 1; a wave wholly past N has none)
+      const bool has_word = (n_raw >> 6) < n_words;
+      const int64_t wi = (int64_t)c * n_words + (has_word ? (n_raw >> 6) : 0);
+      const int32_t base = vis_prefix[wi];
+      pack_row = (int64_t)base + __popcll(vb & ((1ull << lane) - 1ull));
+      if (lane == 0 && has_word) {
+        reinterpret_cast<uint64_t*>(msg + ML.words)[wi] = vb;
+        reinterpret_cast<int32_t*>(msg + ML.prefix)[wi] = base;
+      }
+      if (n_raw == 0) {  // camera centres, once
+        const Cam cam0 = load_cam(viewmats, Ks, c);
+        float cp0[3];
+        cam_center(campos, cam0, c, cp0);
+        float* dst = reinterpret_cast<float*>(msg + ML.campos) + 3 * c;
+        dst[0] = cp0[0]; dst[1] = cp0[1]; dst[2] = cp0[2];
+      }
+    }
     float g_R[9], g_t[3], g_cp[3];
     if constexpr (VIEWGRAD) {
 #pragma unroll
@@ -333,6 +394,13 @@ __global__ __launch_bounds__(256, 2) void projection_bwd_kernel(
         nc = p.color_dim;
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (k < nc) v_colors[idx * nc + k] = vch[k];
+      } else if constexpr (SHSPLIT) {
+        nc = 3;
+        if (pack_row < msg_cap) {
+          float* dst = reinterpret_cast<float*>(msg + ML.vals) + 3 * pack_row;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) dst[k] = (chv[k] > 0.f) ? vch[k] : 0.f;  // clamp_min(c+0.5, 0) gate
+        }
       } else if constexpr (CMODE == GS_COLOR_SH) {
         nc = 3;
         float vrgb[3];
@@ -442,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void projection_bwd_kernel(
           }
           const float st = wave_sum(g_t[i]);
           if (lane == 0) atomicAdd(&v_viewmats[c * 16 + i * 4 + 3], st);
-          if constexpr (CMODE == GS_COLOR_SH) {
+          if constexpr (CMODE == GS_COLOR_SH && !SHSPLIT) {
             const float sp = wave_sum(g_cp[i]);
             if (lane == 0 && v_campos) atomicAdd(&v_campos[c * 3 + i], sp);
           }
@@ -450,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void projection_bwd_kernel(
       }
     }
   }
-  if constexpr (CMODE == GS_COLOR_SH) {
+  if constexpr (CMODE == GS_COLOR_SH && !SHSPLIT) {
     // v_sh [N,K,3]: a lane storing its own 12K-byte row makes every store instruction touch 64 different lines
     // (4x the write requests, measured 0.19 -> 0.17 ms at config 2 and 0.30 -> 0.23 ms at 3 M Gaussians without it).
     // Transpose the wave's rows through LDS, 32 rows at a time, and store them as contiguous 256-B wave rows.
@@ -556,17 +624,18 @@ static int check_params(const gs_proj_params* p) {
 
 }  // namespace gs
 
-#define GS_FWD_ARGS *p, means, quats, scales, opacities, viewmats, Ks, campos, colors, radii, means2d, splats, tiles_per_gauss, covars
+#define GS_FWD_ARGS *p, means, quats, scales, opacities, viewmats, Ks, campos, colors, radii, means2d, splats, tiles_per_gauss, covars, vis_words, vis_counts
 #define GS_FWD_LAUNCH(CM, DG) hipLaunchKernelGGL((gs::projection_fwd_kernel<CM, DG>), grid, block, 0, s, GS_FWD_ARGS)
 
 extern "C" int gs_projection_fwd(const gs_proj_params* p, const float* means, const float* quats,
                                  const float* scales, const float* opacities, const float* viewmats,
                                  const float* Ks, const float* campos, const float* colors, int32_t* radii,
                                  float* means2d, float* splats, int32_t* tiles_per_gauss, const float* covars,
-                                 void* stream) {
+                                 uint64_t* vis_words, int32_t* vis_counts, void* stream) {
   int st = gs::check_params(p);
   if (st != GS_OK) return st;
   if (p->N == 0) return GS_OK;
+  if ((vis_words == nullptr) != (vis_counts == nullptr)) return GS_ERR_INVALID_ARG;
   if (!means || !opacities || !viewmats || !Ks || !radii || !means2d || !splats || !tiles_per_gauss)
     return GS_ERR_INVALID_ARG;
   if (!covars && (!quats || !scales)) return GS_ERR_INVALID_ARG;
@@ -590,7 +659,7 @@ extern "C" int gs_projection_fwd(const gs_proj_params* p, const float* means, co
   return GS_OK;
 }
 
-#define GS_BWD_ARGS *p, means, quats, scales, opacities, viewmats, Ks, campos, colors, radii, splats, v_means2d, ld_v_means2d, v_splats, v_means, v_quats, v_scales, v_opacities, v_colors, v_viewmats, v_campos, covars, v_covars
+#define GS_BWD_ARGS *p, means, quats, scales, opacities, viewmats, Ks, campos, colors, radii, splats, v_means2d, ld_v_means2d, v_splats, v_means, v_quats, v_scales, v_opacities, v_colors, v_viewmats, v_campos, covars, v_covars, (const int32_t*)nullptr, (unsigned char*)nullptr, (int64_t)0, 0
 #define GS_BWD_LAUNCH(CM, DG)                                                                              \
   do {                                                                                                     \
     if (v_viewmats)                                                                                        \
@@ -630,6 +699,41 @@ extern "C" int gs_projection_bwd(const gs_proj_params* p, const float* means, co
         default: GS_BWD_LAUNCH(GS_COLOR_SH, 4); break;
       }
   }
+  GS_CHECK_LAUNCH();
+  return GS_OK;
+}
+
+// ---- split backward: geometry here, SH colours through the packed colour-gradient message ------------------------
+extern "C" int gs_colour_message_layout(int32_t C, int32_t N, int64_t cap, int64_t* out5_host) {
+  if (C < 1 || N < 0 || cap < 0 || !out5_host) return GS_ERR_INVALID_ARG;
+  const gs::MsgLayout L = gs::msg_layout(C, N, cap);
+  out5_host[0] = L.campos; out5_host[1] = L.words; out5_host[2] = L.prefix; out5_host[3] = L.vals; out5_host[4] = L.total;
+  return GS_OK;
+}
+
+extern "C" int gs_projection_bwd_split(const gs_proj_params* p, const float* means, const float* quats,
+                                       const float* scales, const float* opacities, const float* viewmats,
+                                       const float* Ks, const float* campos, const int32_t* radii, const float* splats,
+                                       const float* v_means2d, int64_t ld_v_means2d, const float* v_splats,
+                                       const int32_t* vis_prefix, float* v_means, float* v_quats, float* v_scales,
+                                       float* v_opacities, float* v_viewmats, void* message, int64_t cap,
+                                       int32_t layout_cams, void* stream) {
+  int st = gs::check_params(p);
+  if (st != GS_OK) return st;
+  if (p->color_mode != GS_COLOR_SH || layout_cams < p->C) return GS_ERR_INVALID_ARG;
+  if (p->N == 0) return GS_OK;
+  if (!means || !quats || !scales || !opacities || !viewmats || !Ks || !radii || !splats || !v_means2d || !v_splats ||
+      !vis_prefix || !v_means || !v_quats || !v_scales || !v_opacities || !message || ld_v_means2d < 2 || cap < 0)
+    return GS_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)gs::ceil_div(p->N, 256)), block(256);
+  const float* no_f = nullptr;
+  float* no_o = nullptr;
+#define GS_BWDS_ARGS *p, means, quats, scales, opacities, viewmats, Ks, campos, no_f, radii, splats, v_means2d, ld_v_means2d, v_splats, v_means, v_quats, v_scales, v_opacities, no_o, v_viewmats, no_o, no_f, no_o, vis_prefix, (unsigned char*)message, cap, layout_cams
+  if (v_viewmats)
+    hipLaunchKernelGGL((gs::projection_bwd_kernel<GS_COLOR_SH, 0, true, true>), grid, block, 0, s, GS_BWDS_ARGS);
+  else
+    hipLaunchKernelGGL((gs::projection_bwd_kernel<GS_COLOR_SH, 0, false, true>), grid, block, 0, s, GS_BWDS_ARGS);
   GS_CHECK_LAUNCH();
   return GS_OK;
 }

@@ -76,7 +76,138 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(int64_t n, int K, const flo
   }
 }
 
+// ---- SH backward from packed colour-gradient messages ---------------------------------------------------------------
+// The SH half of gs_projection_bwd_split: v_sh [N,K,3] and the view-direction part of v_means from `n_msgs` messages of
+// the layout of gs_colour_message_layout (projection.hip), `msg_stride` bytes apart: this rank's own message, or every
+// rank's after one all-gather -- the per-(camera, Gaussian) colour gradient is 12 B where the SH-coefficient gradient it
+// expands to is 12 K B, which is what makes the exchange of a camera-sharded data-parallel step cheap
+// (gsplat/distributed.py).  One thread per Gaussian, looping over messages x cameras in a fixed order, so every rank
+// computes bit-identical sums; a camera's visibility word and prefix are wave-uniform, the pair's 12-B value is read at
+// prefix + (set bits below the lane): lanes read consecutive rows.
+struct MsgLayoutSh {
+  int64_t campos, words, prefix, vals;
+};
+
+template <int DEG, bool VIEWGRAD>
+__global__ __launch_bounds__(256) void sh_bwd_packed_kernel(
+    int N, int K, int C, int n_msgs, int64_t msg_stride, int64_t cap, MsgLayoutSh L, const float* __restrict__ means,
+    const float* __restrict__ coeffs, const unsigned char* __restrict__ msgs, float* __restrict__ v_coeffs,
+    float* __restrict__ v_means, int accumulate_means, int local_msg, float* __restrict__ v_campos) {
+  using TL = ShTile<DEG>;
+  constexpr int NB = (DEG + 1) * (DEG + 1);
+  __shared__ float s_t[4 * TL::FLOATS];
+  const int n_raw = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool live = n_raw < N;
+  const int n = live ? n_raw : N - 1;
+  const int n_words = (N + 63) >> 6;
+  const int w = __builtin_amdgcn_readfirstlane(n_raw >> 6);  // wave-uniform: scalar loads of the words below
+  const bool has_word = w < n_words;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const float mu[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
+  float acc[NB * 3];
+#pragma unroll
+  for (int k = 0; k < NB * 3; ++k) acc[k] = 0.f;
+  float vmx = 0.f, vmy = 0.f, vmz = 0.f;
+  for (int m = 0; m < n_msgs && has_word; ++m) {
+    const unsigned char* msg = msgs + (int64_t)m * msg_stride;
+    const uint64_t* words = reinterpret_cast<const uint64_t*>(msg + L.words);
+    const int32_t* prefix = reinterpret_cast<const int32_t*>(msg + L.prefix);
+    const float* vals = reinterpret_cast<const float*>(msg + L.vals);
+    const float* cps = reinterpret_cast<const float*>(msg + L.campos);
+    // cameras of THIS message (ranks may hold different numbers of cameras; the layout is sized for the largest)
+    const int n_cams = min(max(__builtin_amdgcn_readfirstlane(*reinterpret_cast<const int32_t*>(msg)), 0), C);
+    for (int c = 0; c < n_cams; ++c) {
+      const unsigned long long word = words[(int64_t)c * n_words + w];
+      float gx = 0.f, gy = 0.f, gz = 0.f;
+      if (word != 0ull) {  // wave-uniform
+        if (live && ((word >> lane) & 1ull)) {
+          const int64_t row = (int64_t)prefix[(int64_t)c * n_words + w] + __popcll(word & lt_mask);
+          if (row >= 0 && row < cap) {  // (always, for a well-formed message: cap >= its visible pairs)
+            const float v[3] = {vals[3 * row], vals[3 * row + 1], vals[3 * row + 2]};
+            sh_eval_vjp<DEG, true>(coeffs + (int64_t)n * K * 3, mu[0] - cps[3 * c], mu[1] - cps[3 * c + 1],
+                                   mu[2] - cps[3 * c + 2], v, acc, gx, gy, gz);
+            vmx += gx; vmy += gy; vmz += gz;
+          }
+        }
+        if constexpr (VIEWGRAD) {
+          // d colour / d camera centre = -d colour / d mean, summed over the Gaussians (this rank's cameras only)
+          if (m == local_msg) {
+            float sx = -gx, sy = -gy, sz = -gz;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+              sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o);
+            }
+            if (lane == 0) {
+              atomicAdd(&v_campos[3 * c + 0], sx);
+              atomicAdd(&v_campos[3 * c + 1], sy);
+              atomicAdd(&v_campos[3 * c + 2], sz);
+            }
+          }
+        }
+      }
+    }
+  }
+  float* t = s_t + wave * TL::FLOATS;
+  const int row_w = n_raw - lane;
+#pragma unroll 1
+  for (int h = 0; h < 64 / TL::ROWS; ++h) {
+    if (lane / TL::ROWS == h) {
+#pragma unroll
+      for (int k = 0; k < NB * 3; ++k) t[(lane % TL::ROWS) * (TL::NB3 + 1) + k] = acc[k];
+    }
+    const int row0 = row_w + h * TL::ROWS;
+    const int rows = min(TL::ROWS, N - row0);
+    wave_rows_store<TL::NB3>(t, v_coeffs + (int64_t)row0 * K * 3, rows, K * 3, lane);
+  }
+  if (!live) return;
+  if (accumulate_means) {
+    v_means[3 * n] += vmx; v_means[3 * n + 1] += vmy; v_means[3 * n + 2] += vmz;
+  } else {
+    v_means[3 * n] = vmx; v_means[3 * n + 1] = vmy; v_means[3 * n + 2] = vmz;
+  }
+}
+
 }  // namespace gs
+
+extern "C" int gs_colour_message_layout(int32_t C, int32_t N, int64_t cap, int64_t* out5_host);
+
+extern "C" int gs_sh_bwd_packed(int32_t N, int32_t K, int32_t degree, int32_t C, int32_t n_msgs, int64_t msg_stride,
+                                int64_t cap, const float* means, const float* coeffs, const void* messages,
+                                float* v_coeffs, float* v_means, int32_t accumulate_means, int32_t local_msg,
+                                float* v_campos, void* stream) {
+  if (N < 0 || degree < 0 || degree > 4 || (degree + 1) * (degree + 1) > K || C < 1 || n_msgs < 1 || cap < 0)
+    return GS_ERR_INVALID_ARG;
+  if (N == 0) return GS_OK;
+  int64_t lay[5];
+  int st = gs_colour_message_layout(C, N, cap, lay);
+  if (st != GS_OK) return st;
+  if (!means || !coeffs || !messages || !v_coeffs || !v_means || msg_stride < lay[4]) return GS_ERR_INVALID_ARG;
+  if (v_campos && (local_msg < 0 || local_msg >= n_msgs)) return GS_ERR_INVALID_ARG;
+  const gs::MsgLayoutSh L{lay[0], lay[1], lay[2], lay[3]};
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)gs::ceil_div(N, 256)), block(256);
+  const unsigned char* msgs = (const unsigned char*)messages;
+#define GS_SHP_CASE(D)                                                                                              \
+  case D:                                                                                                           \
+    if (v_campos)                                                                                                   \
+      hipLaunchKernelGGL((gs::sh_bwd_packed_kernel<D, true>), grid, block, 0, s, N, K, C, n_msgs, msg_stride, cap, L, \
+                         means, coeffs, msgs, v_coeffs, v_means, accumulate_means, local_msg, v_campos);            \
+    else                                                                                                            \
+      hipLaunchKernelGGL((gs::sh_bwd_packed_kernel<D, false>), grid, block, 0, s, N, K, C, n_msgs, msg_stride, cap, L, \
+                         means, coeffs, msgs, v_coeffs, v_means, accumulate_means, local_msg, v_campos);            \
+    break;
+  switch (degree) {
+    GS_SHP_CASE(0)
+    GS_SHP_CASE(1)
+    GS_SHP_CASE(2)
+    GS_SHP_CASE(3)
+    default:
+      GS_SHP_CASE(4)
+  }
+  GS_CHECK_LAUNCH();
+  return GS_OK;
+}
 
 extern "C" int gs_sh_fwd(int64_t n, int32_t K, int32_t degree, const float* dirs, const float* coeffs,
                          const uint8_t* masks, float* out, void* stream) {

@@ -101,6 +101,29 @@ def _make_params(N, C, width, height, tile_size, eps2d, near_plane, far_plane, r
     return p
 
 
+# How the backward of in-rasterization SH colours (GS_COLOR_SH) is computed:
+#   False  fused: gs_projection_bwd accumulates v_sh over the cameras in registers (one kernel)
+#   True   split: gs_projection_bwd_split (geometry + the packed 12-B colour gradients of the visible pairs) followed by
+#          gs_sh_bwd_packed (v_sh + the view-direction part of v_means from the packed message)
+# A gradient exchange that is active on the calling thread (gsplat.distributed.GradientExchange, mode "colour") always
+# takes the split route: the packed message is what crosses the ranks.
+SPLIT_SH_BACKWARD = False
+
+_tls = threading.local()
+
+
+def current_exchange():
+    """The gsplat.distributed.GradientExchange active on this thread (None outside its `with` block)."""
+    return getattr(_tls, "exchange", None)
+
+
+def colour_message_layout(C: int, N: int, cap: int):
+    """Byte offsets {campos, words, prefix, vals, total} of the packed colour-gradient message (include/gsplat_mi355x.h)."""
+    out = (ctypes.c_int64 * 5)()
+    B.check(B.lib().gs_colour_message_layout(C, N, cap, out), "gs_colour_message_layout")
+    return dict(zip(("campos", "words", "prefix", "vals", "total"), (int(v) for v in out)))
+
+
 class _ProjectSplats(torch.autograd.Function):
     """means/quats/scales/opacities/colours/cameras -> splat records [C,N,16] + means2d [C,N,2]
     (+ radii, tiles_per_gauss, non-differentiable)."""
@@ -123,11 +146,38 @@ class _ProjectSplats(torch.autograd.Function):
         means2d = torch.empty(C, N, 2, device=dev, dtype=torch.float32)
         # rows with radii == 0 are never written nor read (as gsplat's torch.empty projection outputs)
         splats = torch.empty(C, N, B.GS_REC, device=dev, dtype=torch.float32)
+        # split SH backward: the forward also leaves each camera's visibility words; their scanned populations give
+        # every visible pair its row in the packed colour-gradient message of the backward
+        exchange = current_exchange()
+        want_grad = any(t is not None and t.requires_grad for t in (means, quats, scales, opacities, colors, viewmats))
+        split = (params.color_mode == B.GS_COLOR_SH and covars is None and N > 0 and want_grad
+                 and (SPLIT_SH_BACKWARD or (exchange is not None and exchange.packs_colours)))
+        vis_words = vis_counts = None
+        if split:
+            n_words = (N + 63) // 64
+            vis_words = torch.empty(C, n_words, device=dev, dtype=torch.int64)
+            vis_counts = torch.empty(C, n_words, device=dev, dtype=torch.int32)
         with B.device_guard(dev), B.timed("gs_projection_fwd", dev):
             B.check(B.lib().gs_projection_fwd(
                 ctypes.byref(params), B.ptr(means), B.ptr(quats), B.ptr(scales), B.ptr(opacities), B.ptr(viewmats),
                 B.ptr(Ks), B.ptr(campos), B.ptr(colors), B.ptr(radii), B.ptr(means2d), B.ptr(splats), B.ptr(tiles),
-                B.ptr(covars), B.stream_handle(dev)), "gs_projection_fwd")
+                B.ptr(covars), B.ptr(vis_words), B.ptr(vis_counts), B.stream_handle(dev)), "gs_projection_fwd")
+        ctx.split = None
+        if split:
+            vis_prefix, vis_total = exclusive_scan_i32(vis_counts)
+            # the number of visible pairs sizes the message: to the host through pinned memory behind the scan, so
+            # that reading it in backward costs no synchronisation of its own (the forward's n_isects read, later on
+            # this stream, already covers it); with an exchange, the largest count over the ranks
+            # ... and the largest camera count: every rank lays its message out alike
+            stat = torch.cat([vis_total, vis_total.new_full((1,), C)])
+            if exchange is not None:
+                stat = exchange.max_over_ranks(stat)
+            host = torch.empty(2, dtype=torch.int64, pin_memory=True)
+            host.copy_(stat, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(dev))
+            ctx.split = (vis_prefix, host, ready)
+        ctx.exchange = exchange
         ctx.params = params
         ctx.has_colors = colors is not None
         ctx.has_campos = campos is not None
@@ -172,6 +222,11 @@ class _ProjectSplats(torch.autograd.Function):
         need_vm = ctx.needs_input_grad[5] or ctx.needs_input_grad[7]
         v_viewmats = torch.zeros(C, 4, 4, device=dev, dtype=torch.float32) if need_vm else None
         v_campos = torch.zeros(C, 3, device=dev, dtype=torch.float32) if (need_vm and campos is not None) else None
+        ex = ctx.exchange
+        if ctx.split is not None:
+            return _ProjectSplats._backward_split(ctx, means, quats, scales, opacities, colors, viewmats, Ks, campos,
+                                                  radii, splats, v_splats, v_means2d, ld, v_means, v_quats, v_scales,
+                                                  v_opac, v_colors, v_viewmats, v_campos)
         with B.device_guard(dev), B.timed("gs_projection_bwd", dev):
             B.check(B.lib().gs_projection_bwd(
                 ctypes.byref(p), B.ptr(means), B.ptr(quats), B.ptr(scales), B.ptr(opacities), B.ptr(viewmats),
@@ -179,12 +234,56 @@ class _ProjectSplats(torch.autograd.Function):
                 B.ptr(v_splats), B.ptr(v_means), B.ptr(v_quats), B.ptr(v_scales), B.ptr(v_opac), B.ptr(v_colors),
                 B.ptr(v_viewmats), B.ptr(v_campos), B.ptr(covars), B.ptr(v_covars), B.stream_handle(dev)),
                 "gs_projection_bwd")
+        if ex is not None:
+            # dense exchange: SUM over the ranks of every Gaussian-parameter gradient.  Per-camera inputs (viewmats,
+            # [C,N,D] colours) belong to this rank's cameras and stay local.
+            shared_colours = v_colors if p.color_mode in (B.GS_COLOR_N, B.GS_COLOR_SH) else None
+            ex.all_reduce([t for t in (v_means, v_quats, v_scales, v_covars, v_opac, shared_colours)
+                           if t is not None]).wait()
         g = ctx.needs_input_grad
         return (v_means if g[0] else None, v_quats if (g[1] and v_quats is not None) else None,
                 v_scales if (g[2] and v_scales is not None) else None,
                 v_opac if g[3] else None, v_colors if (g[4] and v_colors is not None) else None,
                 v_viewmats if g[5] else None, None, v_campos if (g[7] and v_campos is not None) else None, None,
                 v_covars if (len(g) > 9 and g[9] and v_covars is not None) else None)
+
+    @staticmethod
+    def _backward_split(ctx, means, quats, scales, opacities, colors, viewmats, Ks, campos, radii, splats, v_splats,
+                        v_means2d, ld, v_means, v_quats, v_scales, v_opac, v_colors, v_viewmats, v_campos):
+        """Geometry kernel + packed colour-gradient message -> (all-gather over the ranks) -> SH kernel."""
+        p, ex, dev = ctx.params, ctx.exchange, means.device
+        N, C = p.N, p.C
+        vis_prefix, host, ready = ctx.split
+        ready.synchronize()  # (long complete: recorded before the forward's n_isects read)
+        cap, lay_cams = int(host[0]), int(host[1])
+        assert lay_cams >= C and cap >= 0, (lay_cams, C, cap)
+        lay = colour_message_layout(lay_cams, N, cap)
+        msg = torch.empty(lay["total"], device=dev, dtype=torch.uint8)
+        with B.device_guard(dev), B.timed("gs_projection_bwd", dev):
+            B.check(B.lib().gs_projection_bwd_split(
+                ctypes.byref(p), B.ptr(means), B.ptr(quats), B.ptr(scales), B.ptr(opacities), B.ptr(viewmats),
+                B.ptr(Ks), B.ptr(campos), B.ptr(radii), B.ptr(splats), v_means2d.data_ptr(), ld, B.ptr(v_splats),
+                B.ptr(vis_prefix), B.ptr(v_means), B.ptr(v_quats), B.ptr(v_scales), B.ptr(v_opac), B.ptr(v_viewmats),
+                B.ptr(msg), cap, lay_cams, B.stream_handle(dev)), "gs_projection_bwd_split")
+        n_msgs, local, msgs, work = 1, 0, msg, None
+        if ex is not None:
+            # ONE all-gather of the messages (12 B per visible pair) instead of a 12 K-byte-per-Gaussian all-reduce of
+            # v_sh; the geometry gradients (44 B per Gaussian) are SUM all-reduced behind it while the SH kernel runs
+            msgs, n_msgs, local = ex.all_gather_messages(msg)
+            work = ex.all_reduce([v_means, v_quats, v_scales, v_opac])
+        v_means_sh = torch.empty_like(v_means) if ex is not None else v_means
+        with B.device_guard(dev), B.timed("gs_sh_bwd_packed", dev):
+            B.check(B.lib().gs_sh_bwd_packed(
+                N, p.sh_K, p.sh_degree, lay_cams, n_msgs, lay["total"], cap, B.ptr(means), B.ptr(colors), B.ptr(msgs),
+                B.ptr(v_colors), B.ptr(v_means_sh), int(ex is None), local, B.ptr(v_campos), B.stream_handle(dev)),
+                "gs_sh_bwd_packed")
+        if work is not None:
+            work.wait()
+            v_means.add_(v_means_sh)
+        g = ctx.needs_input_grad
+        return (v_means if g[0] else None, v_quats if g[1] else None, v_scales if g[2] else None,
+                v_opac if g[3] else None, v_colors if g[4] else None, v_viewmats if g[5] else None, None,
+                v_campos if (g[7] and v_campos is not None) else None, None, None)
 
 
 # ----------------------------------------------------------------------------- integer stages
@@ -255,9 +354,6 @@ def isect_tiles_from_splats(splats: Tensor, tiles_per_gauss: Tensor, tile_width:
         tile_n_bits, cam_n_bits = _key_bits(C, tile_width, tile_height)
         isect_ids, flatten_ids = radix_sort_pairs(isect_ids, flatten_ids, 32 + tile_n_bits + cam_n_bits)
     return isect_ids, flatten_ids
-
-
-_tls = threading.local()
 
 
 def set_absgrad_accumulate(on: bool) -> None:

@@ -172,10 +172,19 @@ def main():
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="multi-rank dry run on fewer GPUs than ranks: gloo backend, device = LOCAL_RANK %% device_count "
                          "(exercises the N > 1 code path on a one-GPU box; the number it prints is not a result)")
-    ap.add_argument("--exchange", choices=["auto", "dense"], default="auto",
-                    help="N > 1: how the parameter gradients cross ranks (gsplat.distributed.GradientExchange); "
-                         "'dense' = one SUM all-reduce per parameter tensor")
+    ap.add_argument("--exchange", choices=["auto", "colour", "dense"], default="auto",
+                    help="N > 1: how the parameter gradients cross ranks (gsplat.distributed.GradientExchange): 'colour' "
+                         "(= auto) all-gathers the packed 12-B colour gradients of the visible pairs and rebuilds v_sh on "
+                         "every rank; 'dense' = one SUM all-reduce per parameter tensor")
+    ap.add_argument("--sh-backward", choices=["default", "fused", "split"], default="default",
+                    help="single-GPU route of the in-rasterization SH backward (gsplat.cuda._wrapper.SPLIT_SH_BACKWARD)")
+    ap.add_argument("--dump-stacks-after", type=float, default=0.0,
+                    help="debugging: print every thread's Python stack to stderr after this many seconds (a hung run)")
     args = ap.parse_args()
+    if args.dump_stacks_after > 0:
+        import faulthandler
+
+        faulthandler.dump_traceback_later(args.dump_stacks_after, repeat=False, file=sys.stderr)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
@@ -197,8 +206,13 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
     from gsplat import _backend as B
-    from gsplat.distributed import all_reduce_gradients
+    from gsplat.cuda import _wrapper as Wm
+    from gsplat.distributed import GradientExchange
     from gsplat.rendering import rasterization
+
+    if args.sh_backward != "default":
+        Wm.SPLIT_SH_BACKWARD = args.sh_backward == "split"
+    exchange = GradientExchange(mode=args.exchange)  # (a no-op context on one rank)
 
     N, C, W, H, K, D = args.gaussians, args.cams, args.width, args.height, 16, 4
     headline_shape = (N, C, W, H) == (1_000_000, 5, 1242, 375)
@@ -220,16 +234,18 @@ def main():
     def step():
         for p in plist:
             p.grad = None
-        rc, ra, meta = rasterization(
-            params["means"], params["quats"], params["scales"], params["opacities"], params["colors"], vm, Ks, W, H,
-            near_plane=0.1, far_plane=1e10, sh_degree=3, packed=False, render_mode="RGB+ED", absgrad=True,
-            rasterize_mode="antialiased")
+        with exchange:
+            rc, ra, meta = rasterization(
+                params["means"], params["quats"], params["scales"], params["opacities"], params["colors"], vm, Ks, W,
+                H, near_plane=0.1, far_plane=1e10, sh_degree=3, packed=False, render_mode="RGB+ED", absgrad=True,
+                rasterize_mode="antialiased")
         # fixed random linear functional of colours and alphas, as two dot products
         loss = torch.dot(rc.reshape(-1), wc_flat) + torch.dot(ra.reshape(-1), wa_flat)
+        # N > 1: the gradient exchange runs inside this backward (packed colour gradients all-gathered behind the
+        # geometry kernel, geometry gradients all-reduced while the SH kernel runs); afterwards .grad is the gradient
+        # of all ranks' cameras, on every rank
         loss.backward()
-        if world > 1:
-            note("backward done, all-reduce")
-            all_reduce_gradients(plist)
+        note("backward + gradient exchange queued")
         return meta
 
     note("first step")
@@ -295,7 +311,9 @@ def main():
         # redo launches are folded into their stage's entry point)
         per_kernel = {}
         for k, nbytes in bytes_.items():
-            ms_k = sum(v[1] * v[0] / 3 for kk, v in kern_all.items() if kk == k or kk.startswith(k + "_"))
+            # (the split SH backward's second kernel belongs to the projection-backward stage)
+            ms_k = sum(v[1] * v[0] / 3 for kk, v in kern_all.items() if kk == k or kk.startswith(k + "_")
+                       or (k == "gs_projection_bwd" and kk == "gs_sh_bwd_packed"))
             if ms_k > 0:
                 gbs = nbytes / (ms_k * 1e-3) / 1e9
                 per_kernel[k] = {"ms": round(ms_k, 4), "algorithmic_bytes": nbytes, "GB/s": round(gbs, 1),
@@ -312,9 +330,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "gaussians": N, "cams_per_gpu": C,
                        "width": W, "height": H, "visible_pairs_V": V, "n_isects_I": I,
-                       "parallelism": (f"camera/frame DP x{world}, grad all-reduce "
-                                       f"({'gloo REHEARSAL, not a result' if args.rehearse_gloo else 'RCCL'})")
-                       if world > 1 else "single GPU"},
+                       "parallelism": (f"camera/frame DP x{world}, gradient exchange '{exchange.mode}' "
+                                       f"({'gloo REHEARSAL, not a result' if args.rehearse_gloo else 'RCCL'}), "
+                                       f"{exchange.bytes_sent // max(1, args.steps + args.warmup + 3 + (args.warmup == 0))} "
+                                       "payload bytes contributed per rank and step")
+                       if world > 1 else "single GPU",
+                       "sh_backward": "split" if (Wm.SPLIT_SH_BACKWARD or (world > 1 and exchange.packs_colours))
+                       else "fused"},
             "roofline": roofline,
             "step_hbm_floor": {"algorithmic_bytes_per_step": total_bytes,
                                "frac_of_hbm_peak": round(total_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},

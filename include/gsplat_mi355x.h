@@ -91,6 +91,10 @@ int gs_projection_fwd(const gs_proj_params* p,
                       int32_t* tiles_per_gauss,/* out [C,N]                     */
                       const float* covars,     /* [N,6] world covariances {xx,xy,xz,yy,yz,zz} (gsplat `covars=`) or NULL;
                                                   when given, quats / scales are ignored and may be NULL */
+                      uint64_t* vis_words,     /* out [C, ceil(N/64)] or NULL: bit n%64 of word n/64 = (c, n) visible */
+                      int32_t* vis_counts,     /* out [C, ceil(N/64)] (with vis_words): set bits of each word; its exclusive
+                                                  scan (gs_exclusive_scan_i32) is the `vis_prefix` of gs_projection_bwd_split
+                                                  = the row of each pair in gsplat's packed (c, n) order (A.7) */
                       void* stream);
 
 int gs_projection_bwd(const gs_proj_params* p,
@@ -112,6 +116,42 @@ int gs_projection_bwd(const gs_proj_params* p,
                       const float* covars,     /* [N,6] or NULL, as in the forward (not with GS_COLOR_SH) */
                       float* v_covars,         /* out [N,6] when covars is given (v_quats / v_scales unused) */
                       void* stream);
+
+/* ---- backward split for camera-sharded data parallelism (no reference counterpart: the reference is single-GPU,
+ * R/models/trainers/base.py:411) ------------------------------------------------------------------
+ * With SH colours evaluated inside `rasterization` (GS_COLOR_SH), the SH-coefficient gradient is 12 K bytes per
+ * Gaussian but only rank 1 per camera: basis(dir) (x) v_rgb.  gs_projection_bwd_split does the geometry half of
+ * gs_projection_bwd (v_means without the view-direction term, v_quats, v_scales, v_opacities, v_viewmats without the
+ * camera-centre term) and writes the clamp-gated colour gradient of every visible (camera, Gaussian) pair, 12 B each,
+ * packed in ascending (c, n) order, into a "colour-gradient message":
+ *     [int32 n_cams, 12 B reserved | campos Cl x 3 f32 | words Cl x W u64 | prefix Cl x W i32 | vals cap x 3 f32]
+ * with W = ceil(N / 64) and Cl = `layout_cams` >= this call's C: every rank of an exchange lays its message out for the
+ * largest camera count of any rank, so all messages have one size, and records its own count in n_cams
+ * (sections 256-B aligned; byte offsets from gs_colour_message_layout(Cl, N, cap): {campos, words, prefix, vals, total}).
+ * gs_sh_bwd_packed turns n_msgs such messages, msg_stride bytes apart (this rank's own, or every rank's after ONE
+ * all-gather), into v_sh [N,K,3] and the view-direction part of v_means, in a fixed order (bit-identical on every
+ * rank).  cap >= number of visible pairs (rows beyond cap are dropped). */
+int gs_colour_message_layout(int32_t C, int32_t N, int64_t cap, int64_t* out5_host);
+int gs_projection_bwd_split(const gs_proj_params* p,
+                            const float* means, const float* quats, const float* scales,
+                            const float* opacities, const float* viewmats, const float* Ks,
+                            const float* campos,        /* [C,3] or NULL (derived from viewmats) */
+                            const int32_t* radii, const float* splats,
+                            const float* v_means2d, int64_t ld_v_means2d, const float* v_splats,
+                            const int32_t* vis_prefix,  /* [C, W] exclusive scan of gs_projection_fwd's vis_counts */
+                            float* v_means, float* v_quats, float* v_scales, float* v_opacities,
+                            float* v_viewmats,          /* out [C,4,4] PRE-ZEROED or NULL */
+                            void* message,              /* out, gs_colour_message_layout(layout_cams, N, cap)[4] bytes */
+                            int64_t cap, int32_t layout_cams, void* stream);
+int gs_sh_bwd_packed(int32_t N, int32_t K, int32_t degree, int32_t C /* layout_cams of the messages */, int32_t n_msgs,
+                     int64_t msg_stride, int64_t cap, const float* means, const float* coeffs /* [N,K,3] */,
+                     const void* messages,
+                     float* v_coeffs,           /* out [N,K,3], written whole */
+                     float* v_means,            /* [N,3]: view-direction part of v_means, += when accumulate_means else = */
+                     int32_t accumulate_means,
+                     int32_t local_msg,         /* index of this rank's own message (for v_campos) */
+                     float* v_campos,           /* out [C,3] PRE-ZEROED or NULL: camera-centre gradient of the local cameras */
+                     void* stream);
 
 /* ---- spherical_harmonics --------------------------------------------------------------------- */
 int gs_sh_fwd(int64_t n, int32_t K, int32_t degree,

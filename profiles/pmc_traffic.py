@@ -21,7 +21,7 @@ from collections import defaultdict
 
 KERNELS = {  # bench.py entry-point label -> substring(s) of the HIP kernel names it launches
     "gs_projection_fwd": ["gs::projection_fwd_kernel"],
-    "gs_projection_bwd": ["gs::projection_bwd_kernel"],
+    "gs_projection_bwd": ["gs::projection_bwd_kernel", "gs::sh_bwd_packed_kernel"],
     "gs_isect_bin_count": ["gs::isect_bin_kernel<false>"],
     "gs_isect_bin_scatter": ["gs::isect_bin_kernel<true>", "gs::isect_region_scatter_kernel"],
     "gs_isect_bin_offsets": ["gs::bin_slice_prefix_kernel", "gs::bin_offsets_kernel"],

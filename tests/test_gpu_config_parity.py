@@ -16,7 +16,7 @@ import torch
 
 import oracle
 import synth_scene
-from util import assert_close, close_report
+from util import assert_close, close_report, robust_rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -64,7 +64,7 @@ def test_config1_shape_fwd_and_all_gradients_vs_oracle(gpu_device):
     for k in ["means", "quats", "scales", "opacities", "colors"]:
         assert torch.isfinite(p[k].grad).all()
         frac, rel_l2, _ = close_report(f"cfg0.v_{k}", p[k].grad, go[k].grad)
-        rob = _robust_rel_l2(p[k].grad, go[k].grad, 1e-3)
+        rob = robust_rel_l2(p[k].grad, go[k].grad, 1e-3)
         print(f"[parity] cfg0.v_{k}: rel_l2 without the 0.1 % worst rows {rob:.3e}")
         if not (rel_l2 <= 1.5e-4 and rob <= 5e-5 and frac <= 1.5e-3):
             fails.append((k, rel_l2, rob, frac))
@@ -73,15 +73,6 @@ def test_config1_shape_fwd_and_all_gradients_vs_oracle(gpu_device):
     if not rel_l2 <= 5e-4:
         fails.append(("viewmats", rel_l2, frac))
     assert not fails, fails
-
-
-def _robust_rel_l2(got, ref, drop_frac):
-    """rel-L2 over the rows that remain after dropping the `drop_frac` rows with the largest error."""
-    got = got.detach().double().cpu().reshape(got.shape[0], -1)
-    ref = ref.detach().double().cpu().reshape(ref.shape[0], -1)
-    err = (got - ref).pow(2).sum(1)
-    keep = err.argsort()[: max(1, int(round(err.numel() * (1.0 - drop_frac))))]
-    return float(err[keep].sum().sqrt() / (ref[keep].norm() + 1e-30))
 
 
 def _pick_tiles(lens, C, TW, TH, n_random, seed):
@@ -158,7 +149,7 @@ def test_config2_gradient_spot_check_on_sampled_tiles(gpu_device):
     for k in ["means", "quats", "scales", "opacities", "colors"]:
         got = p[k].grad
         frac, rel_l2, _ = close_report(f"cfg1.tiles.v_{k}", got[gd], sub[k].grad)
-        rob = _robust_rel_l2(got[gd], sub[k].grad, 1e-3)
+        rob = robust_rel_l2(got[gd], sub[k].grad, 1e-3)
         print(f"[parity] cfg1.tiles.v_{k}: rel_l2 without the 0.1 % worst rows {rob:.3e}")
         if not (rel_l2 <= 1.5e-4 and rob <= 5e-5 and frac <= 1.5e-3):
             fails.append((k, rel_l2, rob, frac))

@@ -34,3 +34,14 @@ def assert_close(name, got, ref, atol=ATOL, rtol=RTOL, max_bad_frac=0.0, max_rel
 
 def to_dev(d, dev, dtype=torch.float32):
     return {k: (v.to(dev, dtype) if v.is_floating_point() else v.to(dev)) for k, v in d.items()}
+
+
+def robust_rel_l2(got, ref, drop_frac=1e-3):
+    """rel-L2 over the rows that remain after dropping the `drop_frac` rows with the largest error: a discrete decision
+    that flips at an ulp (alpha < 1/255, T <= 1e-4, ceil of the radius) changes a pixel by up to ~1e-2 and with it the
+    gradient of every Gaussian under that pixel; this is the error with that flip budget left out."""
+    got = got.detach().double().cpu().reshape(got.shape[0], -1)
+    ref = ref.detach().double().cpu().reshape(ref.shape[0], -1)
+    err = (got - ref).pow(2).sum(1)
+    keep = err.argsort()[: max(1, int(round(err.numel() * (1.0 - drop_frac))))]
+    return float(err[keep].sum().sqrt() / (ref[keep].norm() + 1e-30))
