@@ -236,3 +236,30 @@ extern "C" int gs_refine_split_means(int64_t n_out, int32_t scale_mode, const in
   GS_CHECK_LAUNCH();
   return GS_OK;
 }
+
+// ---- opacity reset (VanillaGaussians.refinement_after, R/models/gaussians/vanilla.py:268-280) ----------------------
+//   raw = logit(min(sigmoid(raw), reset_alpha_value));  Adam exp_avg = exp_avg_sq = 0 for the opacity parameter
+// The reference does it with four elementwise torch ops and two zeros_like allocations; here one pass, in place.
+namespace gs {
+__global__ __launch_bounds__(256) void opacity_reset_kernel(int64_t n, float reset_value, float* __restrict__ raw,
+                                                            float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float o = 1.f / (1.f + expf(-raw[i]));
+  const float r = fminf(o, reset_value);
+  raw[i] = logf(r / (1.f - r));  // torch.logit (no eps): +-inf at exactly 0 / 1, as the reference
+  if (exp_avg) exp_avg[i] = 0.f;
+  if (exp_avg_sq) exp_avg_sq[i] = 0.f;
+}
+}  // namespace gs
+
+extern "C" int gs_opacity_reset(int64_t n, float reset_alpha_value, float* raw_opacities, float* exp_avg,
+                                float* exp_avg_sq, void* stream) {
+  if (n < 0 || !(reset_alpha_value > 0.f)) return GS_ERR_INVALID_ARG;
+  if (n == 0) return GS_OK;
+  if (!raw_opacities) return GS_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(gs::opacity_reset_kernel, dim3((unsigned)gs::ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
+                     reset_alpha_value, raw_opacities, exp_avg, exp_avg_sq);
+  GS_CHECK_LAUNCH();
+  return GS_OK;
+}

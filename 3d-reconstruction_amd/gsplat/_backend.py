@@ -20,6 +20,16 @@ _LIB_NAME = "libgsplat_mi355x.so"
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "lib", _LIB_NAME)
 
 
+class PixelLossOpts(Structure):
+    """Mirror of `gs_pixel_loss_opts` (include/gsplat_mi355x.h)."""
+
+    _fields_ = [
+        ("bce_mode", c_int32), ("bce_limit", c_float),
+        ("depth_type", c_int32), ("depth_normalize", c_int32), ("depth_inverse", c_int32),
+        ("depth_reduction", c_int32), ("max_depth", c_float),
+    ]
+
+
 class ProjParams(Structure):
     """Mirror of `gs_proj_params` (include/gsplat_mi355x.h)."""
 
@@ -84,6 +94,14 @@ _SIGNATURES = {
     "gs_pixel_losses_workspace_floats": (c_int64, []),
     "gs_pixel_losses_fwd": (ctypes.c_int, [c_int64, _P, _P, _P, _P, _P, c_float, _P, c_int64, _P, _P]),
     "gs_pixel_losses_bwd": (ctypes.c_int, [c_int64, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P]),
+    "gs_pixel_losses_ex_fwd": (ctypes.c_int, [c_int64, POINTER(PixelLossOpts)] + [_P] * 8 + [c_int64, _P, _P]),
+    "gs_pixel_losses_ex_bwd": (ctypes.c_int, [c_int64, POINTER(PixelLossOpts)] + [_P] * 11),
+    "gs_inv_depth_smooth_fwd": (ctypes.c_int, [c_int32, c_int32, _P, _P, _P, c_int64, _P, _P]),
+    "gs_inv_depth_smooth_bwd": (ctypes.c_int, [c_int32, c_int32, _P, _P, _P, _P, _P]),
+    "gs_region_l1_fwd": (ctypes.c_int, [c_int64, _P, _P, _P, _P, c_float, _P, c_int64, _P, _P]),
+    "gs_region_l1_bwd": (ctypes.c_int, [c_int64, _P, _P, _P, _P, c_float, _P, _P, _P, _P]),
+    "gs_affine_reg": (ctypes.c_int, [c_int32, c_int32, _P, _P, _P, _P, _P]),
+    "gs_opacity_reset": (ctypes.c_int, [c_int64, c_float, _P, _P, _P, _P]),
     "gs_cube_texture_fwd": (ctypes.c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
     "gs_cube_texture_bwd": (ctypes.c_int, [c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
     "gs_mark_visible": (ctypes.c_int, [c_int64, _P, _P, _P]),

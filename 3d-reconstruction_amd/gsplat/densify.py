@@ -156,3 +156,19 @@ def refine_gaussians(params: Dict[str, Tensor], state: Optional[DensifyState], c
     info = {"n_before": n, "n_after": n_out, "n_splits": n_splits, "n_kept_split_children": ns * n_ksplit,
             "n_kept_dups": n_kdup, "n_culled_old": n - n_self}
     return new_p, new_adam, info
+
+
+def reset_opacities(raw_opacities: Tensor, reset_alpha_value: float, adam_state: Optional[dict] = None) -> None:
+    """The opacity reset of `refinement_after` (/root/reference/3D-Reconstruction-main/models/gaussians/vanilla.py:268-280),
+    in place and in one pass: `raw = logit(min(sigmoid(raw), reset_alpha_value))`, and the opacity parameter's Adam
+    moments (`adam_state = optimizer.state[param]` with "exp_avg" / "exp_avg_sq") zeroed where the reference replaces
+    them with `zeros_like`.  `raw_opacities` is the Parameter's `.data` (any shape, fp32, contiguous)."""
+    dev = B.require_gpu(raw_opacities)
+    assert raw_opacities.dtype == torch.float32 and raw_opacities.is_contiguous()
+    ea = adam_state.get("exp_avg") if adam_state else None
+    es = adam_state.get("exp_avg_sq") if adam_state else None
+    for t in (ea, es):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == raw_opacities.numel())
+    with B.device_guard(dev):
+        B.check(B.lib().gs_opacity_reset(raw_opacities.numel(), float(reset_alpha_value), B.ptr(raw_opacities),
+                                         B.ptr(ea), B.ptr(es), B.stream_handle(dev)), "gs_opacity_reset")

@@ -454,6 +454,56 @@ int gs_pixel_losses_bwd(int64_t n, const float* opacity, const float* depth, con
                         const float* g_out /* [4] device */, float* v_opacity, float* v_depth /* or NULL */,
                         void* stream);
 
+/* The same terms in every configuration the reference can be given (R/models/trainers/base.py:231-250,
+ * R/models/losses.py): mask loss "bce" | "safe_bce" (SafeBCE, losses.py:33-83, limit 0.1 at base.py:238), DepthLoss
+ * loss_type l1 | l2 | smooth_l1, normalize, use_inverse_depth, reduction mean_on_hit | mean_on_hw | sum
+ * (losses.py:91-199).  `select` [n] u8 or NULL restricts the depth term to a subset of the selected pixels
+ * (depth_error_percentile, losses.py:163-171: the host ranks `err_map` and passes the keep-mask back); `err_map` [n]
+ * or NULL receives each pixel's depth error (-1 where the pixel is not selected). */
+typedef struct gs_pixel_loss_opts {
+  int32_t bce_mode;        /* 0 binary_cross_entropy, 1 safe_binary_cross_entropy */
+  float bce_limit;         /* safe_bce: limit (0.1) */
+  int32_t depth_type;      /* 0 l1, 1 l2, 2 smooth_l1 */
+  int32_t depth_normalize; /* safe_normalize_depth: clamp(x / max_depth, 1e-6, 1) */
+  int32_t depth_inverse;   /* 1 / x behind the normalisation */
+  int32_t depth_reduction; /* 0 mean_on_hit, 1 mean_on_hw, 2 sum */
+  float max_depth;         /* DepthLoss.upper_bound */
+} gs_pixel_loss_opts;
+int gs_pixel_losses_ex_fwd(int64_t n, const gs_pixel_loss_opts* opts, const float* opacity, const float* depth,
+                           const float* sky_mask, const float* valid_mask, const float* lidar_depth,
+                           const uint8_t* select, float* err_map, float* workspace, int64_t workspace_floats,
+                           float* out /* [4] */, void* stream);
+int gs_pixel_losses_ex_bwd(int64_t n, const gs_pixel_loss_opts* opts, const float* opacity, const float* depth,
+                           const float* sky_mask, const float* valid_mask, const float* lidar_depth,
+                           const uint8_t* select, const float* fwd_out, const float* g_out, float* v_opacity,
+                           float* v_depth /* or NULL */, void* stream);
+
+/* kornia.losses.inverse_depth_smoothness_loss(1 / (depth + 1e-5), image) (R/models/trainers/base.py:575-585; kornia is not
+ * available here: parity unpinned, the published formula restated): depth [H,W], image [H,W,3], out [1];
+ * workspace: gs_pixel_losses_workspace_floats() floats. */
+int gs_inv_depth_smooth_fwd(int32_t H, int32_t W, const float* depth, const float* image, float* workspace,
+                            int64_t workspace_floats, float* out, void* stream);
+int gs_inv_depth_smooth_bwd(int32_t H, int32_t W, const float* depth, const float* image, const float* g_out /* [1] */,
+                            float* v_depth, void* stream);
+
+/* Dynamic-region RGB loss (R/models/trainers/base.py:598-613): mean over the pixels with region > thresh (and
+ * valid_mask != 0) and the 3 channels of |gt * valid - pred * valid|.  out [2] = {loss (0 when no pixel qualifies: the
+ * reference then adds no term), number of pixels}. */
+int gs_region_l1_fwd(int64_t n, const float* pred /* [n,3] */, const float* gt, const float* valid_mask,
+                     const float* region, float thresh, float* workspace, int64_t workspace_floats, float* out,
+                     void* stream);
+int gs_region_l1_bwd(int64_t n, const float* pred, const float* gt, const float* valid_mask, const float* region,
+                     float thresh, const float* fwd_out, const float* g_out /* [1] */, float* v_pred, void* stream);
+
+/* Affine regulariser (R/models/trainers/base.py:587-596): |A[:3,:3] - I|.mean() + |A[:3,3]|.mean() over m matrices of
+ * `rows` x 4 (rows >= 3).  out [1] and / or v_A (same shape as A, rows >= 3 left untouched) from g_out [1]. */
+int gs_affine_reg(int32_t m, int32_t rows, const float* A, const float* g_out, float* out, float* v_A, void* stream);
+
+/* Opacity reset of VanillaGaussians.refinement_after (R/models/gaussians/vanilla.py:268-280), in place:
+ * raw = logit(min(sigmoid(raw), reset_alpha_value)); the opacity parameter's Adam moments (may be NULL) = 0. */
+int gs_opacity_reset(int64_t n, float reset_alpha_value, float* raw_opacities, float* exp_avg, float* exp_avg_sq,
+                     void* stream);
+
 /* ---- sky environment light (next to the path: SURVEY.md 8(f) rank 4) --------------------------------- */
 /* EnvLight.forward (R/models/modules.py:191-203): nvdiffrast.torch.texture(base[None], l, filter_mode='linear',
  * boundary_mode='cube') -- bilinear, seamless cube-map lookup (OpenGL face order +x,-x,+y,-y,+z,-z and orientation).

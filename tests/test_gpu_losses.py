@@ -137,3 +137,149 @@ def test_losses_accept_other_float_dtypes(gpu_device):
     tex = torch.rand(6, 8, 8, 3, dtype=torch.float64, device=dev).requires_grad_(True)
     cube_texture(tex, torch.randn(100, 3, device=dev)).sum().backward()
     assert tex.grad.dtype == torch.float64
+
+
+# --------------------------------------------------------------------------------- every configurable variant
+def _maps(H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    opacity = torch.rand(H, W, 1, generator=g).clamp(1e-4, 1 - 1e-4)
+    opacity[0, :5] = 0.0   # exactly 0 / 1: the clipped ends of both BCE forms
+    opacity[1, :5] = 1.0
+    depth = torch.rand(H, W, 1, generator=g) * 90 + 0.05
+    sky = (torch.rand(H, W, generator=g) > 0.7).float()
+    valid = (torch.rand(H, W, generator=g) > 0.1).float()
+    lidar = torch.where(torch.rand(H, W, generator=g) > 0.6, torch.rand(H, W, generator=g) * 100, torch.zeros(H, W))
+    lidar[2, :7] = depth[2, :7, 0]  # exact hits: |d| = 0 rows of every loss type
+    return opacity, depth, sky, valid, lidar
+
+
+@pytest.mark.parametrize("kind", ["bce", "safe_bce"])
+@pytest.mark.parametrize("loss_type,normalize,inverse,reduction,percentile", [
+    ("l1", False, False, "mean_on_hit", None),
+    ("l2", False, False, "mean_on_hw", None),
+    ("smooth_l1", False, False, "sum", None),
+    ("l1", True, False, "mean_on_hit", None),
+    ("l2", True, True, "mean_on_hit", None),
+    ("smooth_l1", True, True, "mean_on_hw", None),
+    ("l1", False, False, "mean_on_hit", 0.95),
+    ("l2", True, False, "sum", 0.5),
+])
+def test_pixel_loss_variants_match_reference_lines(gpu_device, kind, loss_type, normalize, inverse, reduction, percentile):
+    """safe_bce and every DepthLoss configuration against oracle/loss_ref.py (the reference's lines, fp64 autograd)."""
+    from gsplat.losses import pixel_losses
+    from oracle import loss_ref as R
+
+    dev = gpu_device
+    H, W = 61, 83
+    opacity, depth, sky, valid, lidar = _maps(H, W, 11)
+    od, dd = opacity.double().requires_grad_(True), depth.double().requires_grad_(True)
+    ref_m = R.mask_loss(od, sky.double(), valid.double(), kind)
+    ref_d = R.depth_loss(dd, lidar.double(), valid.double(), loss_type, normalize, inverse, percentile, 80.0, reduction)
+    (0.7 * ref_m + 1.3 * ref_d).backward()
+
+    og, dg = opacity.to(dev).requires_grad_(True), depth.to(dev).requires_grad_(True)
+    out = pixel_losses(og, dg, sky.to(dev), valid.to(dev), lidar.to(dev), 80.0, opacity_loss_type=kind,
+                       depth_loss_type=loss_type, normalize=normalize, inverse_depth=inverse, reduction=reduction,
+                       depth_error_percentile=percentile)
+    (0.7 * out["sky_bce"] + 1.3 * out["depth_l1"] + 0.0 * out["opacity_entropy"]).backward()
+    tol = lambda r: 2e-5 * max(1.0, abs(float(r)))
+    assert abs(float(out["sky_bce"]) - float(ref_m)) <= tol(ref_m), (float(out["sky_bce"]), float(ref_m))
+    assert abs(float(out["depth_l1"]) - float(ref_d)) <= 5 * tol(ref_d), (float(out["depth_l1"]), float(ref_d))
+    for name, got, ref in (("v_opacity", og.grad, od.grad), ("v_depth", dg.grad, dd.grad)):
+        err = float((got.cpu().double() - ref).abs().max())
+        assert err <= 1e-4 * float(ref.abs().max()) + 1e-12, (name, err, float(ref.abs().max()))
+
+
+def test_depth_error_map_is_reduction_none(gpu_device):
+    from gsplat.losses import depth_error_map
+    from oracle import loss_ref as R
+
+    H, W = 40, 50
+    opacity, depth, sky, valid, lidar = _maps(H, W, 3)
+    m = depth_error_map(depth.to(gpu_device), lidar.to(gpu_device), valid.to(gpu_device), 80.0, "l2", True, False)
+    ref = R.depth_loss(depth.double(), lidar.double(), valid.double(), "l2", True, False, None, 80.0, "none")
+    got = m.cpu().reshape(-1)
+    got = got[got >= 0].double()
+    assert got.numel() == ref.numel() and torch.allclose(got, ref, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("H,W", [(37, 52), (2, 2), (120, 200)])
+def test_inverse_depth_smoothness(gpu_device, H, W):
+    """kornia's formula (parity unpinned: oracle/loss_ref.py restates it) and its gradient w.r.t. the depth."""
+    from gsplat.losses import inverse_depth_smoothness
+    from oracle import loss_ref as R
+
+    g = torch.Generator().manual_seed(H)
+    depth = torch.rand(H, W, 1, generator=g) * 40 + 0.5
+    image = torch.rand(H, W, 3, generator=g)
+    dd = depth.double().requires_grad_(True)
+    ref = R.inverse_depth_smoothness(dd, image.double())
+    ref.backward()
+    dg = depth.to(gpu_device).requires_grad_(True)
+    out = inverse_depth_smoothness(dg, image.to(gpu_device))
+    out.backward()
+    assert abs(float(out) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    err = float((dg.grad.cpu().double() - dd.grad).abs().max())
+    assert err <= 1e-4 * float(dd.grad.abs().max()) + 1e-12
+
+
+def test_dynamic_region_and_affine_terms(gpu_device):
+    from gsplat.losses import affine_regulariser, dynamic_region_l1
+    from oracle import loss_ref as R
+
+    dev = gpu_device
+    g = torch.Generator().manual_seed(8)
+    H, W = 45, 70
+    rgb, pix = torch.rand(H, W, 3, generator=g), torch.rand(H, W, 3, generator=g)
+    valid = (torch.rand(H, W, generator=g) > 0.2).float()
+    dyn = torch.rand(H, W, 1, generator=g)
+    rd = rgb.double().requires_grad_(True)
+    ref = R.dynamic_region_loss(rd, pix.double(), valid.double(), dyn.double())
+    ref.backward()
+    rg = rgb.to(dev).requires_grad_(True)
+    loss, cnt = dynamic_region_l1(rg, pix.to(dev), dyn.to(dev), valid.to(dev))
+    loss.backward()
+    assert int(cnt) == int(((dyn[..., 0] > 0.2) & valid.bool()).sum())
+    assert abs(float(loss) - float(ref)) <= 2e-6
+    assert float((rg.grad.cpu().double() - rd.grad).abs().max()) <= 1e-4 * float(rd.grad.abs().max())
+    # empty region: an exact zero, zero gradient (the reference adds no term)
+    rg2 = rgb.to(dev).requires_grad_(True)
+    loss2, cnt2 = dynamic_region_l1(rg2, pix.to(dev), torch.zeros(H, W, 1, device=dev), valid.to(dev))
+    loss2.backward()
+    assert float(loss2) == 0.0 and int(cnt2) == 0 and float(rg2.grad.abs().max()) == 0.0
+
+    for shape in [(3, 4), (1, 4, 4), (5, 3, 4)]:
+        A = torch.randn(*shape, generator=g) * 0.3
+        if shape[-2] >= 3:
+            A[..., :3, :3] += torch.eye(3)
+        A[..., 0, 0] = 1.0  # an exact match: sign(0) = 0
+        ad = A.double().requires_grad_(True)
+        ref = R.affine_loss(ad)
+        ref.backward()
+        ag = A.to(dev).requires_grad_(True)
+        out = affine_regulariser(ag)
+        out.backward()
+        assert abs(float(out) - float(ref)) <= 2e-6, shape
+        assert torch.allclose(ag.grad.cpu().double(), ad.grad, atol=1e-6), shape
+
+
+def test_opacity_reset_in_place(gpu_device):
+    """raw = logit(min(sigmoid(raw), reset)) and zeroed Adam moments (vanilla.py:268-280)."""
+    from gsplat.densify import reset_opacities
+    from oracle import loss_ref as R
+
+    dev = gpu_device
+    g = torch.Generator().manual_seed(1)
+    raw = torch.randn(100_003, 1, generator=g) * 3
+    ref = R.opacity_reset(raw.double(), 0.01)
+    p = raw.to(dev)
+    state = {"exp_avg": torch.randn(100_003, 1, device=dev), "exp_avg_sq": torch.rand(100_003, 1, device=dev),
+             "step": torch.tensor(7.0)}
+    reset_opacities(p, 0.01, state)
+    assert torch.allclose(p.cpu().double(), ref, rtol=2e-6, atol=2e-6)
+    assert float(state["exp_avg"].abs().max()) == 0.0 and float(state["exp_avg_sq"].abs().max()) == 0.0
+    assert float(torch.sigmoid(p).max()) <= 0.01 * (1 + 1e-5)
+    untouched = raw.to(dev)
+    reset_opacities(untouched, 0.9999)  # above these opacities: unchanged up to the fp32 logit(sigmoid(.)) round trip
+    mid = raw.abs() < 6
+    assert torch.allclose(untouched.cpu()[mid], raw[mid], rtol=1e-3, atol=1e-3)
