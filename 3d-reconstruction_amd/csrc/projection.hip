@@ -149,25 +149,55 @@ __device__ __forceinline__ Proj2D persp_proj(const Cam& cam, const float mc[3], 
 
 // ------------------------------------------------------------------------------------------ forward
 template <int CMODE, int DEG>
-__global__ __launch_bounds__(256) void projection_fwd_kernel(
+__global__ __launch_bounds__(256, (CMODE == GS_COLOR_SH && DEG == 4) ? 1 : 4) void projection_fwd_kernel(
     gs_proj_params p, const float* __restrict__ means, const float* __restrict__ quats,
     const float* __restrict__ scales, const float* __restrict__ opacities, const float* __restrict__ viewmats,
     const float* __restrict__ Ks, const float* __restrict__ campos, const float* __restrict__ colors,
     int32_t* __restrict__ radii, float* __restrict__ means2d, float* __restrict__ splats,
     int32_t* __restrict__ tiles_per_gauss, const float* __restrict__ covars, uint64_t* __restrict__ vis_words,
     int32_t* __restrict__ vis_counts) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= p.N) return;
+  // whole waves stay alive (cooperative loads below); lanes past N are clamped and never store
+  __shared__ float s_tile[4][192];
+  const int n_raw = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int64_t row0 = n_raw - lane;
+  const int rows = (int)min((int64_t)64, (int64_t)p.N - row0);  // wave-uniform
+  if (rows <= 0) return;
+  const bool live = n_raw < p.N;
+  const int n = live ? n_raw : p.N - 1;
   const int n_words = (p.N + 63) >> 6;
-  const float mu[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
+  float* tile = s_tile[threadIdx.x >> 6];
+  float mu[3];
+#ifdef GS_EXP_NOCOOP_FWD
+  const bool coop_ok = false;
+#else
+  const bool coop_ok = true;
+#endif
+  load3(means, coop_ok && aligned16(means), n, row0, rows, lane, tile, mu);
+  // SH coefficients: the whole row up front (aligned float4 loads in flight behind the geometry), not inside the
+  // per-camera branch where every visible camera would wait for them again
+  constexpr int NB3 = (CMODE == GS_COLOR_SH) ? 3 * (DEG + 1) * (DEG + 1) : 1;
+  float creg[NB3];
+#ifndef GS_EXP_NOPREFETCH
+  if constexpr (CMODE == GS_COLOR_SH)
+    sh_load_row<NB3>(colors + (int64_t)n * p.sh_K * 3, (p.sh_K % 4 == 0) && aligned16(colors), creg);
+#endif
   const float opac = opacities[n];
   float S[6];
   if (covars) {  // precomputed world covariances (gsplat `covars=`), upper triangle {xx,xy,xz,yy,yz,zz}
 #pragma unroll
     for (int i = 0; i < 6; ++i) S[i] = covars[6 * n + i];
   } else {
-    const float q[4] = {quats[4 * n], quats[4 * n + 1], quats[4 * n + 2], quats[4 * n + 3]};
-    const float sc[3] = {scales[3 * n], scales[3 * n + 1], scales[3 * n + 2]};
+    float q[4];
+    if (aligned16(quats)) {
+      const float4 q4 = reinterpret_cast<const float4*>(quats)[n];
+      q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q[i] = quats[4 * n + i];
+    }
+    float sc[3];
+    load3(scales, coop_ok && aligned16(scales), n, row0, rows, lane, tile, sc);
     float Rq[9], qn[4], inv_norm;
     quat_to_rot(q, Rq, qn, inv_norm);
     covar3d(Rq, sc, S);
@@ -181,7 +211,7 @@ __global__ __launch_bounds__(256) void projection_fwd_kernel(
     float mc[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) mc[i] = cam.R[i * 3] * mu[0] + cam.R[i * 3 + 1] * mu[1] + cam.R[i * 3 + 2] * mu[2] + cam.t[i];
-    bool ok = (mc[2] >= p.near_plane) && (mc[2] <= p.far_plane);
+    bool ok = live && (mc[2] >= p.near_plane) && (mc[2] <= p.far_plane);
     Proj2D pr;
     float radius = 0.f;
     if (ok) {
@@ -207,9 +237,11 @@ __global__ __launch_bounds__(256) void projection_fwd_kernel(
       }
     }
     if (!ok) {
-      radii[idx] = 0;
-      tiles_per_gauss[idx] = 0;
-      reinterpret_cast<float2*>(means2d)[idx] = make_float2(0.f, 0.f);
+      if (live) {
+        radii[idx] = 0;
+        tiles_per_gauss[idx] = 0;
+        reinterpret_cast<float2*>(means2d)[idx] = make_float2(0.f, 0.f);
+      }
       continue;
     }
     // tile bounding box (isect_tiles pass 1, fp32 exactly as Appendix A.3)
@@ -236,7 +268,10 @@ __global__ __launch_bounds__(256) void projection_fwd_kernel(
       float rgb[3];
       float cp[3];
       cam_center(campos, cam, c, cp);
-      sh_eval<DEG>(colors + (int64_t)n * p.sh_K * 3, mu[0] - cp[0], mu[1] - cp[1], mu[2] - cp[2], rgb);
+#ifdef GS_EXP_NOPREFETCH
+      sh_load_row<NB3>(colors + (int64_t)n * p.sh_K * 3, (p.sh_K % 4 == 0) && aligned16(colors), creg);
+#endif
+      sh_eval<DEG>(creg, mu[0] - cp[0], mu[1] - cp[1], mu[2] - cp[2], rgb);
 #pragma unroll
       for (int k = 0; k < 3; ++k) ch[k] = fmaxf(rgb[k] + 0.5f, 0.f);
     }
@@ -300,8 +335,20 @@ __global__ __launch_bounds__(256, SHSPLIT ? 4 : 2) void projection_bwd_kernel(
   constexpr int NB = (CMODE == GS_COLOR_SH && !SHSPLIT) ? (DEG + 1) * (DEG + 1) : 1;
   const int n_raw = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = n_raw < p.N;
-  const int n = live ? n_raw : p.N - 1;  // keep whole waves alive for the VIEWGRAD reductions
-  const float mu[3] = {means[3 * n], means[3 * n + 1], means[3 * n + 2]};
+  const int n = live ? n_raw : p.N - 1;  // keep whole waves alive (VIEWGRAD reductions, cooperative loads / stores)
+  __shared__ float s_tile3[4][192];
+  float* tile3 = s_tile3[threadIdx.x >> 6];
+  const int lane3 = threadIdx.x & 63;
+  const int64_t row0_3 = n_raw - lane3;
+  const int rows3 = (int)max((int64_t)0, min((int64_t)64, (int64_t)p.N - row0_3));  // wave-uniform
+  // (measured: the cooperative [N,3] transfers that help the forward cost this kernel 0.004-0.006 ms)
+#ifdef GS_EXP_COOP_BWD
+  const bool coop3 = rows3 > 0;
+#else
+  const bool coop3 = false;
+#endif
+  float mu[3];
+  load3(means, aligned16(means) && coop3, n, row0_3, rows3, lane3, tile3, mu);
   const float opac = opacities[n];
   float Rq[9], qn[4], inv_norm = 0.f, S[6];
   float sc[3] = {0.f, 0.f, 0.f};
@@ -309,9 +356,15 @@ __global__ __launch_bounds__(256, SHSPLIT ? 4 : 2) void projection_bwd_kernel(
 #pragma unroll
     for (int i = 0; i < 6; ++i) S[i] = covars[6 * n + i];
   } else {
-    const float q[4] = {quats[4 * n], quats[4 * n + 1], quats[4 * n + 2], quats[4 * n + 3]};
+    float q[4];
+    if (aligned16(quats)) {
+      const float4 q4 = reinterpret_cast<const float4*>(quats)[n];
+      q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+    } else {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) sc[i] = scales[3 * n + i];
+      for (int i = 0; i < 4; ++i) q[i] = quats[4 * n + i];
+    }
+    load3(scales, aligned16(scales) && coop3, n, row0_3, rows3, lane3, tile3, sc);
     quat_to_rot(q, Rq, qn, inv_norm);
     covar3d(Rq, sc, S);
   }
@@ -330,9 +383,26 @@ __global__ __launch_bounds__(256, SHSPLIT ? 4 : 2) void projection_bwd_kernel(
     if (n_raw == 0) *reinterpret_cast<int32_t*>(msg) = p.C;
   }
 
+  // the radii of up to RCH cameras are fetched together, ahead of the camera loop: one dependent round trip
+  // (radius -> branch -> record loads) fewer per camera
+#ifndef GS_EXP_NO_RADII_PREFETCH
+  constexpr int RCH = 8;
+  int rad[RCH];
+#endif
   for (int c = 0; c < p.C; ++c) {
     const int64_t idx = (int64_t)c * p.N + n;
+#ifndef GS_EXP_NO_RADII_PREFETCH
+    if ((c % RCH) == 0) {
+#pragma unroll
+      for (int k = 0; k < RCH; ++k) rad[k] = (c + k < p.C) ? radii[(int64_t)(c + k) * p.N + n] : 0;
+    }
+    int rc = rad[0];
+#pragma unroll
+    for (int k = 1; k < RCH; ++k) rc = ((c % RCH) == k) ? rad[k] : rc;
+    const bool vis = live && (rc > 0);
+#else
     const bool vis = live && (radii[idx] > 0);
+#endif
     int64_t pack_row = 0;  // SHSPLIT: this pair's row of the packed values
     if constexpr (SHSPLIT) {
       const unsigned long long vb = __ballot(vis);
@@ -538,9 +608,8 @@ __global__ __launch_bounds__(256, SHSPLIT ? 4 : 2) void projection_bwd_kernel(
       wave_rows_store<NB3>(t, v_colors + (int64_t)row0 * K3, min(ROWS, p.N - row0), K3, lane);
     }
   }
-  if (!live) return;
-
   if (covars) {
+    if (!live) return;
     // gradient w.r.t. the 6 upper-triangle parameters: an off-diagonal one sits at (i,j) and (j,i) of Sigma
     v_covars[6 * n + 0] = v_S[0]; v_covars[6 * n + 1] = 2.f * v_S[1]; v_covars[6 * n + 2] = 2.f * v_S[2];
     v_covars[6 * n + 3] = v_S[3]; v_covars[6 * n + 4] = 2.f * v_S[4]; v_covars[6 * n + 5] = v_S[5];
@@ -579,12 +648,16 @@ __global__ __launch_bounds__(256, SHSPLIT ? 4 : 2) void projection_bwd_kernel(
   vq[2] = 2.f * (x * (vR[3] + vR[1]) - 2.f * y * (vR[0] + vR[8]) + z * (vR[7] + vR[5]) + w * (vR[2] - vR[6]));
   vq[3] = 2.f * (x * (vR[6] + vR[2]) + y * (vR[7] + vR[5]) - 2.f * z * (vR[0] + vR[4]) + w * (vR[3] - vR[1]));
   const float dq = vq[0] * w + vq[1] * x + vq[2] * y + vq[3] * z;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) v_quats[4 * n + k] = (vq[k] - dq * qn[k]) * inv_norm;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    v_means[3 * n + k] = v_mu[k];
-    v_scales[3 * n + k] = v_sc[k];
+  // [N,3] gradients leave as the wave's 768 contiguous bytes (gs_common.hpp, wave_store3); every lane takes part
+  store3(v_means, aligned16(v_means) && coop3, n, live, row0_3, rows3, lane3, tile3, v_mu);
+  store3(v_scales, aligned16(v_scales) && coop3, n, live, row0_3, rows3, lane3, tile3, v_sc);
+  if (!live) return;
+  const float4 vq4 = make_float4((vq[0] - dq * qn[0]) * inv_norm, (vq[1] - dq * qn[1]) * inv_norm,
+                                 (vq[2] - dq * qn[2]) * inv_norm, (vq[3] - dq * qn[3]) * inv_norm);
+  if (aligned16(v_quats)) {
+    reinterpret_cast<float4*>(v_quats)[n] = vq4;
+  } else {
+    v_quats[4 * n] = vq4.x; v_quats[4 * n + 1] = vq4.y; v_quats[4 * n + 2] = vq4.z; v_quats[4 * n + 3] = vq4.w;
   }
   v_opacities[n] = v_op;
   if constexpr (CMODE == GS_COLOR_N) {

@@ -166,6 +166,28 @@ __device__ __forceinline__ void sh_basis_vjp(float x, float y, float z, const fl
   }
 }
 
+// One Gaussian's NB3 = 3 (deg + 1)^2 coefficient floats into registers.  With `vec` (row base 16-B aligned: K % 4 == 0 and
+// an aligned tensor) as aligned float4 loads, all issued back to back; otherwise dword loads.  Left to itself the compiler
+// merges `coeffs[3 k + c]` into dwordx4 / dwordx3 loads at 4-B-aligned offsets, which stream a third slower
+// (scratch/ubench/readbw.hip: 4.5 vs 6.6 TB/s on 192-B rows).
+template <int NB3>
+__device__ __forceinline__ void sh_load_row(const float* __restrict__ row, bool vec, float* __restrict__ c) {
+  if (vec) {
+    constexpr int N4 = NB3 / 4;
+    const float4* r4 = reinterpret_cast<const float4*>(row);
+#pragma unroll
+    for (int k = 0; k < N4; ++k) {
+      const float4 v = r4[k];
+      c[4 * k] = v.x; c[4 * k + 1] = v.y; c[4 * k + 2] = v.z; c[4 * k + 3] = v.w;
+    }
+#pragma unroll
+    for (int k = N4 * 4; k < NB3; ++k) c[k] = row[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < NB3; ++k) c[k] = row[k];
+  }
+}
+
 // colour = sum_k b_k(dir/|dir|) * coeffs[k][ch]; coeffs points at this Gaussian's [K][3] block.
 template <int DEG>
 __device__ __forceinline__ void sh_eval(const float* __restrict__ coeffs, float dx, float dy, float dz,
