@@ -19,18 +19,38 @@ __global__ __launch_bounds__(256) void sh_fwd_kernel(int64_t n, int K, const flo
                                                      const float* __restrict__ coeffs,
                                                      const uint8_t* __restrict__ masks,
                                                      float* __restrict__ out) {
-  // each lane streams its own row: the read side is already at what a pure-read stream reaches on this part
-  // (3.7 TB/s here; a torch reduction over the same bytes 3.8), and with fewer bands in use than K a lane only
-  // touches the lines it needs -- the cooperative LDS route (measured) gains nothing at degree 3 and loses below it
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float o[3] = {0.f, 0.f, 0.f};
-  if (masks == nullptr || masks[i]) {
-    sh_eval<DEG>(coeffs + i * K * 3, dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], o);
+  // each lane streams its own coefficient row as aligned float4s, all issued back to back (sh_load_row: the compiler's own
+  // merge of `coeffs[3 k + c]` is a 4-B-aligned dwordx4 / dwordx3 mix that streams a third slower); the 12-B dirs / out
+  // rows move as the wave's 768 contiguous bytes (gs_common.hpp).  With fewer bands in use than K a lane only touches
+  // the lines it needs.
+  __shared__ float s_tile[4][192];
+  constexpr int NB3 = 3 * (DEG + 1) * (DEG + 1);
+  const int64_t i_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int64_t row0 = i_raw - lane;
+  const int rows = (int)min((int64_t)64, n - row0);  // wave-uniform
+  if (rows <= 0) return;
+  const bool live = i_raw < n;
+  const int64_t i = live ? i_raw : n - 1;
+  float* tile = s_tile[threadIdx.x >> 6];
+  const bool on = masks == nullptr || masks[i];
+  float creg[NB3];
+#pragma unroll
+  for (int k = 0; k < NB3; ++k) creg[k] = 0.f;
+  if (on) sh_load_row<NB3>(coeffs + i * K * 3, (K % 4 == 0) && aligned16(coeffs), creg);
+  float d[3];
+  if (aligned16(dirs)) {
+    wave_load3(dirs, row0, rows, lane, tile, d);
+  } else {
+    d[0] = dirs[3 * i]; d[1] = dirs[3 * i + 1]; d[2] = dirs[3 * i + 2];
   }
-  out[3 * i] = o[0];
-  out[3 * i + 1] = o[1];
-  out[3 * i + 2] = o[2];
+  float o[3] = {0.f, 0.f, 0.f};
+  if (on) sh_eval<DEG>(creg, d[0], d[1], d[2], o);
+  if (aligned16(out)) {
+    wave_store3(out, row0, rows, lane, tile, o);
+  } else if (live) {
+    out[3 * i] = o[0]; out[3 * i + 1] = o[1]; out[3 * i + 2] = o[2];
+  }
 }
 
 template <int DEG, bool DIRGRAD>
