@@ -124,6 +124,57 @@ def cpu_baseline(threads: int):
     }
 
 
+def run_render(args, dev, rank, world):
+    """BASELINE configs[4]: render-only, packed, a --views trajectory at --width x --height sharded contiguously over
+    the ranks (no collective on the data path: every rank holds all Gaussians and writes its own frames), frames
+    converted to uint8 on the device and copied to pinned host memory behind the next batch's render
+    (gsplat.harness.render_trajectory; the reference's loop is video_utils.py:647-706).  A step = one pass over the
+    trajectory; value = all ranks' pixels / max-over-ranks time, D2H copy of the frames included."""
+    from gsplat.harness import render_trajectory
+
+    N, W, H, V = args.gaussians, args.width, args.height, args.views
+    g = {k: v.to(dev) for k, v in synth_scene.make_gaussians(N, sh_degree=3, seed=42).items()}
+    cams = [synth_scene.make_cameras(1, W, H, frame=f % 120) for f in range(V)]
+    vm = torch.cat([c[0] for c in cams]).to(dev)
+    Ks = torch.cat([c[1] for c in cams]).to(dev)
+    out = [None]
+
+    def step():
+        out[0], views = render_trajectory(g["means"], g["quats"], g["scales"], g["opacities"], g["colors"], vm, Ks, W,
+                                          H, sh_degree=3, views_per_call=args.views_per_call, rank=rank,
+                                          world_size=world, near_plane=0.1, out=out[0])
+        return views
+
+    for _ in range(max(1, args.warmup)):
+        views = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_gloo else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "Mpix/s render-only (NOT the headline metric)", "value": round(V * W * H * args.steps / dt / 1e6, 1),
+            "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup),
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "views_per_s": round(V * args.steps / dt, 1),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[4]: {N} Gaussians, SH deg 3, {V}-view {W}x{H} trajectory, packed, no "
+                                   f"gradients, views sharded over {world} rank(s) ({len(views)} on rank 0), "
+                                   f"{args.views_per_call} views per call, uint8 frames copied to pinned host memory",
+                       "gaussians": N, "views": V, "width": W, "height": H,
+                       "parallelism": f"view sharding x{world}, no collective" if world > 1 else "single GPU"}}),
+              flush=True)
+
+
 def spawn_ranks(n: int) -> int:
     """Bare `python bench.py --gpus N` (no launcher): start the N ranks as fresh child processes of this, still
     GPU-free, process (nothing here has called into HIP: importing torch does not), one device per rank, rendezvous on
@@ -161,12 +212,23 @@ def spawn_ranks(n: int) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--steps", type=int, default=None, help="default 20 (train, frames) / 2 (render)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 5 (train, frames) / 1 (render)")
+    ap.add_argument("--mode", choices=["train", "frames", "render"], default="train",
+                    help="train = the headline (BASELINE configs[1]; every rank one fixed 5-camera frame); frames = "
+                         "configs[3] (--frames frames x --cams cameras sharded by frame over the ranks, a new frame every "
+                         "step, densification statistics kept per step and all-reduced every --refine-interval steps); "
+                         "render = configs[4] (render-only packed trajectory of --views views sharded over the ranks, "
+                         "frames copied to pinned host memory; a step = one pass over the trajectory).  Only 'train' at "
+                         "its default shape prints the headline metric")
+    ap.add_argument("--gaussians", type=int, default=None, help="default 1M (train, frames) / 6M (render)")
     ap.add_argument("--cams", type=int, default=5)
-    ap.add_argument("--width", type=int, default=1242)
-    ap.add_argument("--height", type=int, default=375)
+    ap.add_argument("--width", type=int, default=None, help="default 1242 (train, frames) / 1920 (render)")
+    ap.add_argument("--height", type=int, default=None, help="default 375 (train, frames) / 1080 (render)")
+    ap.add_argument("--frames", type=int, default=120)
+    ap.add_argument("--views", type=int, default=600)
+    ap.add_argument("--views-per-call", type=int, default=3)
+    ap.add_argument("--refine-interval", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=4)
     ap.add_argument("--rehearse-gloo", action="store_true",
@@ -181,6 +243,11 @@ def main():
     ap.add_argument("--dump-stacks-after", type=float, default=0.0,
                     help="debugging: print every thread's Python stack to stderr after this many seconds (a hung run)")
     args = ap.parse_args()
+    render = args.mode == "render"
+    for name, train_default, render_default in (("steps", 20, 2), ("warmup", 5, 1), ("gaussians", 1_000_000, 6_000_000),
+                                                ("width", 1242, 1920), ("height", 375, 1080)):
+        if getattr(args, name) is None:
+            setattr(args, name, render_default if render else train_default)
     if args.dump_stacks_after > 0:
         import faulthandler
 
@@ -210,17 +277,35 @@ def main():
     from gsplat.distributed import GradientExchange
     from gsplat.rendering import rasterization
 
+    if render:
+        run_render(args, dev, rank, world)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if args.sh_backward != "default":
         Wm.SPLIT_SH_BACKWARD = args.sh_backward == "split"
     exchange = GradientExchange(mode=args.exchange)  # (a no-op context on one rank)
 
     N, C, W, H, K, D = args.gaussians, args.cams, args.width, args.height, 16, 4
-    headline_shape = (N, C, W, H) == (1_000_000, 5, 1242, 375)
+    headline_shape = (N, C, W, H) == (1_000_000, 5, 1242, 375) and args.mode == "train"
     g = synth_scene.make_gaussians(N, sh_degree=3, seed=42)
     params = {k: v.to(dev).requires_grad_(True) for k, v in g.items()}
-    # weak scaling: rank r renders frame r of the 5-camera rig (ego advances 0.5 m per frame)
-    vm, Ks = synth_scene.make_cameras(C, W, H, frame=rank)
-    vm, Ks = vm.to(dev), Ks.to(dev)
+    if args.mode == "frames":
+        # configs[3]: the frames of the sequence shard contiguously over the ranks; every step renders the next frame
+        # of this rank's shard (all its cameras), so camera poses -- and with them visibility, list lengths and the
+        # exchange's message -- change from step to step as they do in training
+        from gsplat.densify import DensifyState, accumulate_stats
+        from gsplat.distributed import all_reduce_densification_stats, shard_views
+
+        mine = shard_views(args.frames, rank, world)
+        assert len(mine) > 0, "more ranks than frames"
+        cams = [synth_scene.make_cameras(C, W, H, frame=f) for f in mine]
+        cams = [(a.to(dev), b.to(dev)) for a, b in cams]
+        dstate = DensifyState()
+    else:
+        # weak scaling: rank r renders frame r of the 5-camera rig (ego advances 0.5 m per frame)
+        cams = [tuple(t.to(dev) for t in synth_scene.make_cameras(C, W, H, frame=rank))]
+    n_steps = [0]
     gen = torch.Generator().manual_seed(1 + rank)
     wc = torch.randn(C, H, W, D, generator=gen).to(dev)
     wa = torch.randn(C, H, W, 1, generator=gen).to(dev)
@@ -234,6 +319,8 @@ def main():
     def step():
         for p in plist:
             p.grad = None
+        vm, Ks = cams[n_steps[0] % len(cams)]
+        n_steps[0] += 1
         with exchange:
             rc, ra, meta = rasterization(
                 params["means"], params["quats"], params["scales"], params["opacities"], params["colors"], vm, Ks, W,
@@ -246,6 +333,12 @@ def main():
         # of all ranks' cameras, on every rank
         loss.backward()
         note("backward + gradient exchange queued")
+        if args.mode == "frames":
+            # VanillaGaussians.after_train every step (vanilla.py:154-182), its three statistics summed / maxed over
+            # the ranks when the refinement is due (every rank then takes the same split / duplicate / cull decisions)
+            accumulate_stats(meta, dstate, absgrad=True)
+            if n_steps[0] % args.refine_interval == 0:
+                all_reduce_densification_stats(dstate.xys_grad_norm, dstate.vis_counts, dstate.max_2Dsize)
         return meta
 
     note("first step")
@@ -319,10 +412,13 @@ def main():
                 per_kernel[k] = {"ms": round(ms_k, 4), "algorithmic_bytes": nbytes, "GB/s": round(gbs, 1),
                                  "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
         total_bytes = sum(bytes_.values())
-        headline = (N, C, W, H) == (1_000_000, 5, 1242, 375)
-        workload = (("configs[1]: " if headline else "NOT the headline shape: ") +
+        headline = headline_shape and args.mode == "train"
+        workload = (("configs[1]: " if headline else "NOT the headline: ") +
                     f"{N} Gaussians, SH deg 3, {C} cams {W}x{H} batched fwd+bwd, RGB+ED, absgrad + antialiased, "
-                    "packed=False")
+                    "packed=False" +
+                    (f"; configs[3]: {args.frames} frames sharded by frame over {world} rank(s), a new frame every step, "
+                     f"densification statistics every step, all-reduced every {args.refine_interval} steps"
+                     if args.mode == "frames" else ""))
         out = {
             "metric": "Mpix/s fwd+bwd, 1M Gaussians @375x1242x5 cams" if headline else "Mpix/s fwd+bwd", "value": round(value, 3), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),

@@ -7,7 +7,13 @@ the per-launch HBM bytes bench.py reports as roofline.traffic.
     python profiles/pmc_traffic.py gpurun_out/pmc_rd gpurun_out/pmc_wr > profiles/traffic.json
 
 Units and corrections (/opt/skills/guides/MI355X_MICROARCH.md, "HBM"): both counters are in KiB; on gfx950 FETCH_SIZE
-tallies each 128-B fabric read request as 64 B, so wide coalesced reads show exactly half their bytes -> doubled here;
+tallies every fabric read request as 64 B whether it fetches 64 B or 128 B, so wide coalesced reads (128-B requests)
+show exactly half their bytes -> doubled here, while a kernel whose reads are gathers of single 64-B records issues
+64-B requests and its RAW counter is already exact (profiles/r02_fetch_calibration.txt: scratch/ubench/gather64.hip,
+kernels of known byte count -- streaming 1 GiB reads 0.5 GiB raw; gathers of 64-B records, whole or 48 B or 16 B of
+each, read 1.00 GiB raw = the lines touched).  The two rasterizer kernels are gather-dominated (the splat records they
+read by id; forward 94 % of its read bytes): for them `read_bytes_per_launch` is the raw count plus the known coalesced
+streams counted once more (ids, and in the backward the per-pixel inputs), and `read_bytes_upper` the doubled value.
 WRITE_SIZE is exact for streaming stores and float atomics.  The x2 read correction is checked in the same pass against a
 kernel of known byte count (rocBLAS dot over the loss weights: 2 x 4 x C*H*W*D bytes) and the write unit against the
 torch fill of the gradient record (C*N*64 bytes); both ratios are printed into the JSON as `calibration`.
@@ -29,6 +35,11 @@ KERNELS = {  # bench.py entry-point label -> substring(s) of the HIP kernel name
     "gs_rasterize_fwd": ["gs::rasterize_fwd_kernel"],
     "gs_rasterize_bwd": ["gs::rasterize_bwd_kernel"],
 }
+
+
+# entry points whose reads are mostly per-id gathers of 64-B splat records: label -> coalesced bytes per step that the
+# raw counter shows at half (filled in from the shape below)
+GATHER_DOMINATED = ("gs_rasterize_fwd", "gs_rasterize_bwd")
 
 
 def per_kernel(directory, counter):
@@ -60,10 +71,20 @@ def main():
         fetch = sum(v[1] for k, v in rd.items() if any(s in k for s in subs))
         write = sum(v[1] for k, v in wr.items() if any(s in k for s in subs))
         launches = max([v[0] for k, v in rd.items() if any(s in k for s in subs)] or [0])
+        read = fetch * 1024 * 2
+        extra = {}
+        if label in GATHER_DOMINATED:
+            # coalesced streams of the kernel (128-B requests, shown at half): the backward's per-pixel inputs
+            # (render_alphas, final_T, last_ids, v_colors [D], v_alphas); the id lists are a few % and left in the raw
+            stream = C * H * W * 4 * (D + 4) if label == "gs_rasterize_bwd" else 0
+            read = fetch * 1024 + stream / 2
+            extra = {"read_bytes_upper": int(fetch * 1024 * 2),
+                     "read_note": "gather-dominated: raw FETCH_SIZE (64-B requests are counted exactly) + half of the "
+                                  "known coalesced per-pixel streams; read_bytes_upper = the doubled counter"}
         out["kernels"][label] = {
             "fetch_size_kib_raw": round(fetch, 1), "write_size_kib_raw": round(write, 1),
-            "read_bytes_per_launch": int(fetch * 1024 * 2), "write_bytes_per_launch": int(write * 1024),
-            "hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024), "launches_seen": launches,
+            "read_bytes_per_launch": int(read), "write_bytes_per_launch": int(write * 1024),
+            "hbm_bytes_per_launch": int(read + write * 1024), "launches_seen": launches, **extra,
         }
     for k, v in rd.items():
         if "rocblas_dot_kernel" in k:  # reads two [C,H,W,D] / [C,H,W,1] fp32 vectors per call, alternately
