@@ -21,6 +21,7 @@
 // segment before step 4, which the sort then fixes completely.  HBM traffic: 2 reads of the visible records,
 // one 8-B write + read and one 12-B write per intersection.
 #include "gs_common.hpp"
+#include "raster_cull.hpp"
 
 namespace gs {
 
@@ -33,27 +34,79 @@ constexpr int BIN_MAX_TILES = 16384;    // per camera: LDS histogram of 64 KiB
 // A workgroup streams its row slice 1024 rows at a time.  Most rows of a camera are culled (tiles_per_gauss == 0),
 // so the visible ones are first compacted into an LDS queue {row id, tile box, depth bits} and the tile walk then
 // runs on full waves.  cnt[] is the camera's tile histogram (count) or the per-tile write cursor (scatter).
-constexpr int BIN_QCAP = 2 * BIN_THREADS;
 
-template <bool SCATTER>
-__device__ __forceinline__ void bin_drain(uint32_t* cnt, const uint4* q, int qn, int tile_w, uint2* __restrict__ pairs) {
+// CULL (count pass only): a (row, tile) pair is counted only if the splat can reach alpha >= 1/255 on some pixel of
+// the tile (rect_may_touch over the tile's 16x16 pixel centres, the rasterizer's own whole-tile test).  Dropping the
+// others changes no output bit of the rasterizer -- every pixel skips them (A.5) -- but shortens the lists the
+// scatter writes, the sort orders and both rasterizer passes stage.  The decision is taken ONCE, here: a box of up to
+// 64 tiles leaves a bit mask (bit t = tile t of the box in row-major order) beside its visible-list entry and the
+// scatter follows the mask, so the two passes agree by construction; larger boxes (rare) are not culled.
+struct CullRec {
+  float mx, my, A, Bh, C, op;
+};
+
+// One wave walks the tile boxes of up to 64 visible-list entries, one per lane (`valid`): histogram / cursor updates in
+// `cnt`.  Returns the lane's tile mask (CULL).
+template <bool SCATTER, bool CULL>
+__device__ __forceinline__ unsigned long long bin_walk(uint32_t* cnt, bool valid, const uint4 en, const CullRec g,
+                                                       int tile_w, float tile_px, uint2* __restrict__ pairs) {
   const int lane = threadIdx.x & 63;
-  for (int e0 = (threadIdx.x >> 6) * 64; e0 < qn; e0 += BIN_THREADS) {
-    const int e = e0 + lane;
+  {
     int cntg = 0, x0 = 0, y0 = 0, x1 = 0;
     uint32_t idx = 0, dbits = 0;
-    if (e < qn) {
-      const uint4 en = q[e];
+    if (valid) {
       idx = en.x; dbits = en.w;
       x0 = en.y & 0xffff; y0 = en.y >> 16; x1 = en.z & 0xffff;
       cntg = (int)((en.z >> 16) - y0) * (x1 - x0);
     }
-    if (cntg > 0 && cntg <= BIN_COOP) {
+    unsigned long long mask = 0ull;
+    if (!CULL && cntg > 0 && cntg <= BIN_COOP) {
       int tj = x0, trow0 = y0 * tile_w;
       for (int t = 0; t < cntg; ++t) {
         const uint32_t pos = atomicAdd(&cnt[trow0 + tj], 1u);
         if (SCATTER) pairs[pos] = make_uint2(dbits, idx);
         if (++tj == x1) { tj = x0; trow0 += tile_w; }
+      }
+    }
+    if (CULL && cntg > 0 && cntg <= BIN_COOP) {
+      // Small box, one lane: per tile ROW the columns the splat can reach.  The region {alpha >= 1/255} is the ellipse
+      // pw(dx, dy) >= L, L = log2(tau / opacity) (minus the slack of rect_may_touch, taken over the whole box); cut by
+      // the row's strip of pixel centres it is convex, so its x-extent is an interval whose ends are reached at the
+      // ellipse's x-extreme points (dy = -+ Bh xmax / C) clamped into the strip.  Same decision as rect_may_touch per
+      // tile up to rounding, both conservative (0.01 px margin here); a row costs one evaluation instead of one per tile.
+      const float ext = tile_px - 1.f;
+      const int w = x1 - x0, y1 = y0 + cntg / w;
+      const float Dx = fmaxf(fabsf(g.mx - ((float)x0 * tile_px + 0.5f)), fabsf(g.mx - ((float)x1 * tile_px - 0.5f)));
+      const float Dy = fmaxf(fabsf(g.my - ((float)y0 * tile_px + 0.5f)), fabsf(g.my - ((float)y1 * tile_px - 0.5f)));
+      const float slack = 1e-5f * (fabsf(g.A) * Dx * Dx + fabsf(g.C) * Dy * Dy) + 1e-2f;
+      const float L = __builtin_amdgcn_logf(ALPHA_MIN * 0.999f * __builtin_amdgcn_rcpf(g.op)) - slack;  // log2
+      const float det = g.A * g.C - g.Bh * g.Bh;
+      // a record the projection never writes for a visible row (NaN, non-definite conic) -> every tile, as rect_may_touch
+      const bool sane = (g.A < 0.f) && (g.C < 0.f) && (det > 0.f) && (g.op > 0.f) && (L == L) && (fabsf(L) < 3.0e38f);
+      const float rdet = __builtin_amdgcn_rcpf(det), rA = __builtin_amdgcn_rcpf(g.A);
+      const float ymax2 = g.A * L * rdet;
+      const float xmax = __builtin_amdgcn_sqrtf(fmaxf(0.f, g.C * L * rdet));
+      const float dyr = -g.Bh * xmax * __builtin_amdgcn_rcpf(g.C);
+      const float rtile = __builtin_amdgcn_rcpf(tile_px);
+      int trow0 = y0 * tile_w, sh = 0;
+      for (int ti = y0; ti < y1; ++ti, trow0 += tile_w, sh += w) {
+        int lo = x0, hi = x1 - 1;
+        if (sane) {
+          const float dyh = g.my - ((float)ti * tile_px + 0.5f), dyl = dyh - ext;
+          const float dyn = fminf(fmaxf(0.f, dyl), dyh);
+          const float dy1 = fminf(fmaxf(dyr, dyl), dyh), dy2 = fminf(fmaxf(-dyr, dyl), dyh);
+          const float r = -g.Bh * dy1 * rA - __builtin_amdgcn_sqrtf(fmaxf(0.f, g.A * L - dy1 * dy1 * det)) * rA;
+          const float l = -g.Bh * dy2 * rA + __builtin_amdgcn_sqrtf(fmaxf(0.f, g.A * L - dy2 * dy2 * det)) * rA;
+          const float m = 1e-2f + 1e-6f * (fabsf(r) + fabsf(l) + fabsf(g.mx));
+          const float xlo = g.mx - r - m, xhi = g.mx - l + m;  // pixel centres the splat can reach in this row
+          lo = max(x0, (int)ceilf((xlo - 0.5f - ext) * rtile));
+          hi = min(x1 - 1, (int)floorf((xhi - 0.5f) * rtile));
+          if (!(L < 0.f) || dyn * dyn > ymax2 * 1.0001f + 1e-3f) hi = lo - 1;
+        }
+        for (int tj = lo; tj <= hi; ++tj) {
+          atomicAdd(&cnt[trow0 + tj], 1u);
+          mask |= 1ull << (sh + tj - x0);
+        }
       }
     }
     unsigned long long big = __ballot(cntg > BIN_COOP);
@@ -63,16 +116,36 @@ __device__ __forceinline__ void bin_drain(uint32_t* cnt, const uint4* q, int qn,
       const int b_cnt = __shfl(cntg, src), b_x0 = __shfl(x0, src), b_y0 = __shfl(y0, src);
       const int b_w = __shfl(x1, src) - b_x0;
       const uint32_t b_d = __shfl(dbits, src), b_idx = __shfl(idx, src);
+      if (CULL && b_cnt <= 64) {
+        const float mx = __shfl(g.mx, src), my = __shfl(g.my, src), A = __shfl(g.A, src), Bh = __shfl(g.Bh, src);
+        const float Cc = __shfl(g.C, src), op = __shfl(g.op, src);
+        const int ti = b_y0 + lane / b_w, tj = b_x0 + lane % b_w;
+        const bool hit = lane < b_cnt && rect_may_touch(mx, my, A, Bh, Cc, op, (float)tj * tile_px + 0.5f,
+                                                        (float)ti * tile_px + 0.5f, tile_px - 1.f);
+        const unsigned long long bal = __ballot(hit);
+        if (hit) atomicAdd(&cnt[ti * tile_w + tj], 1u);
+        if (lane == src) mask = bal;
+        continue;
+      }
       for (int t = lane; t < b_cnt; t += 64) {
         const int ti = b_y0 + t / b_w, tj = b_x0 + t % b_w;
         const uint32_t pos = atomicAdd(&cnt[ti * tile_w + tj], 1u);
         if (SCATTER) pairs[pos] = make_uint2(b_d, b_idx);
       }
     }
+    return mask;
   }
 }
 
-template <bool SCATTER>
+// Every WAVE keeps a private ring of 128 queue slots and walks the tile boxes of 64 entries whenever it holds that many:
+// the walk always runs on full waves however few rows of a step are visible, and no workgroup barrier is needed between
+// the first and the last step (a workgroup-wide queue drained every 2048 rows filled 6 of 16 waves at 20 % visibility
+// and cost three barriers per drain).  The visible-list segment of the slice is appended 64 entries at a time, in
+// whatever order the waves get there; the order of a slice's list only decides the slot of a pair inside its tile
+// segment before the sort, which fixes it.
+constexpr int BIN_RING = 128;
+
+template <bool SCATTER, bool CULL>
 __global__ __launch_bounds__(BIN_THREADS) void isect_bin_kernel(int32_t N, int32_t tile_w, int32_t T, int32_t n_slices,
                                                                 int32_t rows_per_slice,
                                                                 const float* __restrict__ splats,
@@ -81,25 +154,53 @@ __global__ __launch_bounds__(BIN_THREADS) void isect_bin_kernel(int32_t N, int32
                                                                 const int32_t* __restrict__ offsets,
                                                                 uint2* __restrict__ pairs,
                                                                 uint4* __restrict__ vis_list,
-                                                                int32_t* __restrict__ vis_cnt) {
+                                                                int32_t* __restrict__ vis_cnt,
+                                                                uint2* __restrict__ vis_mask, float tile_px) {
+  static_assert(!(SCATTER && CULL), "the cull decision is taken by the count pass");
   extern __shared__ uint32_t cnt[];  // [T]
-  __shared__ uint4 q[BIN_QCAP];
-  __shared__ int q_n;
+  __shared__ uint4 q[BIN_THREADS / 64][BIN_RING];
+  __shared__ int s_written;
   const int c = blockIdx.y, slice = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   uint32_t* trow = table + ((int64_t)c * n_slices + slice) * T;
   for (int t = tid; t < T; t += BIN_THREADS) cnt[t] = SCATTER ? (uint32_t)offsets[(int64_t)c * T + t] + trow[t] : 0u;
-  if (tid == 0) q_n = 0;
+  if (tid == 0) s_written = 0;
   __syncthreads();
   const int n0 = slice * rows_per_slice;
   const int n1 = min(N, n0 + rows_per_slice);
   // count pass only: the slice's queue entries also go to its segment of vis_list, which the region scatter reads
   const bool keep = !SCATTER && vis_list != nullptr;
   uint4* seg = keep ? vis_list + ((int64_t)c * n_slices + slice) * rows_per_slice : nullptr;
-  int written = 0;
+  uint2* mseg = CULL ? vis_mask + ((int64_t)c * n_slices + slice) * rows_per_slice : nullptr;
+  uint4* qw = q[tid >> 6];
+  int head = 0, tail = 0;  // ring positions (monotone; slot = position & (BIN_RING - 1)), wave-uniform
+
+  auto drain = [&](int n) {  // walk ring entries [head, head + n), n <= 64
+    const bool valid = lane < n;
+    uint4 en = make_uint4(0u, 0u, 0u, 0u);
+    CullRec g = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+      en = qw[(head + lane) & (BIN_RING - 1)];
+      if (CULL) {  // the record's mean / conic / opacity: its line was read for the box a few steps ago
+        const float4* rp = reinterpret_cast<const float4*>(splats + (int64_t)en.x * REC);
+        const float4 r0 = rp[0], r1 = rp[1];
+        g = {r0.x, r0.y, CONIC_SCALE * r0.z, CONIC_SCALE * r0.w, CONIC_SCALE * r1.x, r1.y};
+      }
+    }
+    int base = 0;
+    if (keep) {
+      if (lane == 0) base = atomicAdd(&s_written, n);
+      base = __shfl(base, 0);
+      if (valid) seg[base + lane] = en;
+    }
+    const unsigned long long mask = bin_walk<SCATTER, CULL>(cnt, valid, en, g, tile_w, tile_px, pairs);
+    if (CULL && valid) mseg[base + lane] = make_uint2((uint32_t)mask, (uint32_t)(mask >> 32));
+    head += n;
+  };
+
   // software pipeline over the 1024-row steps: a step's tile counts are loaded two steps ahead and its visible rows'
-  // records one step ahead, so the gathers of step k+1 are in flight while step k is queued and drained
+  // boxes one step ahead, so the gathers of step k+1 are in flight while step k is queued and walked
   auto count_of = [&](int row) { return row < n1 ? tiles_per_gauss[(int64_t)c * N + row] : 0; };
   int cntg = count_of(n0 + tid), cnt_next = count_of(n0 + BIN_THREADS + tid);
   float4 r3 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -121,33 +222,22 @@ __global__ __launch_bounds__(BIN_THREADS) void isect_bin_kernel(int32_t N, int32
     }
     const int cnt_nn = count_of(nb + 2 * BIN_THREADS + tid);
     const unsigned long long vm = __ballot(vis);
-    int qbase = 0;
-    if (lane == 0 && vm) qbase = atomicAdd(&q_n, __popcll(vm));
-    qbase = __shfl(qbase, 0);
     if (vis)
-      q[qbase + __popcll(vm & lt_mask)] =
+      qw[(tail + __popcll(vm & lt_mask)) & (BIN_RING - 1)] =
           make_uint4((uint32_t)idx, (uint32_t)__float_as_int(r3.y), (uint32_t)__float_as_int(r3.z), dbits);
+    tail += __popcll(vm);
     cntg = cnt_next; cnt_next = cnt_nn; r3 = r3_next; dbits = dbits_next;
-    // a block appends at most BIN_THREADS entries, so draining every QCAP/256 blocks (a data-independent, workgroup-uniform
-    // decision) can never overflow the queue
-    const int it = (nb - n0) / BIN_THREADS;
-    if ((it % (BIN_QCAP / BIN_THREADS)) == (BIN_QCAP / BIN_THREADS) - 1 || nb + BIN_THREADS >= n1) {
-      __syncthreads();
-      const int qn = q_n;
-      if (keep) {
-        for (int e = tid; e < qn; e += BIN_THREADS) seg[written + e] = q[e];
-        written += qn;
-      }
-      bin_drain<SCATTER>(cnt, q, qn, tile_w, pairs);
-      __syncthreads();
-      if (tid == 0) q_n = 0;
-      __syncthreads();
-    }
+    // (the ring is written and read by this wave only: LDS operations of one wave complete in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (tail - head >= 64) drain(64);  // at most 63 + 64 entries are ever pending: one walk per step suffices
   }
+  if (tail > head) drain(tail - head);
   if (!SCATTER) {
     __syncthreads();
     for (int t = tid; t < T; t += BIN_THREADS) trow[t] = cnt[t];
-    if (keep && tid == 0) vis_cnt[c * n_slices + slice] = written;
+    if (keep && tid == 0) vis_cnt[c * n_slices + slice] = s_written;
   }
 }
 
@@ -158,10 +248,12 @@ __global__ __launch_bounds__(BIN_THREADS) void isect_bin_kernel(int32_t N, int32
 // visible lists (written by the count pass: 16 B per visible row, contiguous) clipped to its band, and so writes runs
 // G * R times as long from a cursor table R times smaller.  Which slot a hit gets inside its tile segment differs from
 // the slice scatter's; the per-tile sort that follows fixes the order completely either way.
+// CULL: the count pass's tile masks (see bin_drain) say which tiles of a box of <= 64 tiles take the pair.
+template <bool CULL>
 __global__ __launch_bounds__(BIN_THREADS) void isect_region_scatter_kernel(
     int32_t tile_w, int32_t tile_h, int32_t T, int32_t n_slices, int32_t G, int32_t R, int32_t seg_cap,
-    const uint4* __restrict__ vis_list, const int32_t* __restrict__ vis_cnt, const uint32_t* __restrict__ table,
-    const int32_t* __restrict__ offsets, uint2* __restrict__ pairs) {
+    const uint4* __restrict__ vis_list, const int32_t* __restrict__ vis_cnt, const uint2* __restrict__ vis_mask,
+    const uint32_t* __restrict__ table, const int32_t* __restrict__ offsets, uint2* __restrict__ pairs) {
   extern __shared__ uint32_t cur[];  // [band tiles]
   const int c = blockIdx.y, g = blockIdx.x / R, r = blockIdx.x - g * R;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -177,23 +269,53 @@ __global__ __launch_bounds__(BIN_THREADS) void isect_region_scatter_kernel(
   for (int s = s0; s < s1; ++s) {
     const int n = vis_cnt[c * n_slices + s];
     const uint4* seg = vis_list + ((int64_t)c * n_slices + s) * seg_cap;
+    const uint2* mseg = CULL ? vis_mask + ((int64_t)c * n_slices + s) * seg_cap : nullptr;
     for (int e0 = (tid >> 6) * 64; e0 < n; e0 += BIN_THREADS) {
       const int e = e0 + lane;
-      int cntg = 0, x0 = 0, y0 = 0, x1 = 0;
+      int cntg = 0, x0 = 0, y0 = 0, x1 = 0, rows = 0;
       uint32_t idx = 0, dbits = 0;
+      unsigned long long m = 0ull;  // CULL: the band's part of the tile mask, bit 0 = tile (x0, y0)
+      bool masked = false;
       if (e < n) {
         const uint4 en = seg[e];
         idx = en.x; dbits = en.w;
         x0 = en.y & 0xffff; x1 = en.z & 0xffff;
-        y0 = max((int)(en.y >> 16), ty0);
-        cntg = max(0, min((int)(en.z >> 16), ty1) - y0) * (x1 - x0);
+        const int y0o = (int)(en.y >> 16), y1o = (int)(en.z >> 16), w = x1 - x0;
+        y0 = max(y0o, ty0);
+        rows = max(0, min(y1o, ty1) - y0);
+        cntg = rows * w;
+        if (CULL && (y1o - y0o) * w <= 64) {
+          masked = true;
+          if (cntg > 0) {
+            const uint2 mm = mseg[e];
+            m = (((unsigned long long)mm.y << 32) | mm.x) >> ((y0 - y0o) * w);
+            if (cntg < 64) m &= (1ull << cntg) - 1ull;
+          }
+          cntg = __popcll(m);  // pairs this lane will write
+        }
       }
       if (cntg > 0 && cntg <= BIN_COOP) {
-        int tj = x0, trow0 = (y0 - ty0) * tile_w;
-        for (int t = 0; t < cntg; ++t) {
-          const uint32_t pos = atomicAdd(&cur[trow0 + tj], 1u);
-          pairs[pos] = make_uint2(dbits, idx);
-          if (++tj == x1) { tj = x0; trow0 += tile_w; }
+        if (CULL && masked) {
+          const int w = x1 - x0;
+          const unsigned long long wmask = w < 64 ? (1ull << w) - 1ull : ~0ull;
+          int base = (y0 - ty0) * tile_w + x0;
+          for (int rr = 0; rr < rows; ++rr, base += tile_w) {
+            unsigned long long rb = m & wmask;
+            m >>= (w & 63);
+            while (rb) {
+              const int j = __ffsll((long long)rb) - 1;
+              rb &= rb - 1;
+              const uint32_t pos = atomicAdd(&cur[base + j], 1u);
+              pairs[pos] = make_uint2(dbits, idx);
+            }
+          }
+        } else {
+          int tj = x0, trow0 = (y0 - ty0) * tile_w;
+          for (int t = 0; t < cntg; ++t) {
+            const uint32_t pos = atomicAdd(&cur[trow0 + tj], 1u);
+            pairs[pos] = make_uint2(dbits, idx);
+            if (++tj == x1) { tj = x0; trow0 += tile_w; }
+          }
         }
       }
       unsigned long long big = __ballot(cntg > BIN_COOP);
@@ -203,6 +325,16 @@ __global__ __launch_bounds__(BIN_THREADS) void isect_region_scatter_kernel(
         const int b_cnt = __shfl(cntg, src), b_x0 = __shfl(x0, src), b_y0 = __shfl(y0, src) - ty0;
         const int b_w = __shfl(x1, src) - b_x0;
         const uint32_t b_d = __shfl(dbits, src), b_idx = __shfl(idx, src);
+        if (CULL && __shfl((int)masked, src)) {
+          const uint32_t mlo = __shfl((uint32_t)m, src), mhi = __shfl((uint32_t)(m >> 32), src);
+          const unsigned long long bm = ((unsigned long long)mhi << 32) | mlo;
+          if ((bm >> lane) & 1ull) {
+            const int ti = b_y0 + lane / b_w, tj = b_x0 + lane % b_w;
+            const uint32_t pos = atomicAdd(&cur[ti * tile_w + tj], 1u);
+            pairs[pos] = make_uint2(b_d, b_idx);
+          }
+          continue;
+        }
         for (int t = lane; t < b_cnt; t += 64) {
           const int ti = b_y0 + t / b_w, tj = b_x0 + t % b_w;
           const uint32_t pos = atomicAdd(&cur[ti * tile_w + tj], 1u);
@@ -834,16 +966,26 @@ extern "C" int32_t gs_isect_bin_slice_rows(int32_t N, int32_t n_slices) {
 
 extern "C" int gs_isect_bin_count(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, const float* splats,
                                   const int32_t* tiles_per_gauss, int32_t n_slices, uint32_t* table,
-                                  uint64_t* vis_list, int32_t* vis_counts, void* stream) {
+                                  uint64_t* vis_list, int32_t* vis_counts, uint64_t* vis_masks, int32_t tile_size,
+                                  void* stream) {
   int st = bin_check(C, N, tile_w, tile_h, n_slices);
   if (st != GS_OK) return st;
   if (!table || (N > 0 && (!splats || !tiles_per_gauss))) return GS_ERR_INVALID_ARG;
   if ((vis_list == nullptr) != (vis_counts == nullptr) || ((uintptr_t)vis_list & 15)) return GS_ERR_INVALID_ARG;
+  if (vis_masks && (!vis_list || tile_size < 1 || ((uintptr_t)vis_masks & 7))) return GS_ERR_INVALID_ARG;
   const int T = tile_w * tile_h;
-  hipLaunchKernelGGL((gs::isect_bin_kernel<false>), dim3((unsigned)n_slices, (unsigned)C), dim3(gs::BIN_THREADS),
-                     (size_t)T * sizeof(uint32_t), (hipStream_t)stream, N, tile_w, T, n_slices,
-                     bin_slice_rows(N, n_slices), splats, tiles_per_gauss, table, (const int32_t*)nullptr,
-                     (uint2*)nullptr, reinterpret_cast<uint4*>(vis_list), vis_counts);
+  const dim3 grid((unsigned)n_slices, (unsigned)C);
+  const size_t lds = (size_t)T * sizeof(uint32_t);
+  const int rows = bin_slice_rows(N, n_slices);
+  if (vis_masks)
+    hipLaunchKernelGGL((gs::isect_bin_kernel<false, true>), grid, dim3(gs::BIN_THREADS), lds, (hipStream_t)stream, N,
+                       tile_w, T, n_slices, rows, splats, tiles_per_gauss, table, (const int32_t*)nullptr,
+                       (uint2*)nullptr, reinterpret_cast<uint4*>(vis_list), vis_counts,
+                       reinterpret_cast<uint2*>(vis_masks), (float)tile_size);
+  else
+    hipLaunchKernelGGL((gs::isect_bin_kernel<false, false>), grid, dim3(gs::BIN_THREADS), lds, (hipStream_t)stream, N,
+                       tile_w, T, n_slices, rows, splats, tiles_per_gauss, table, (const int32_t*)nullptr,
+                       (uint2*)nullptr, reinterpret_cast<uint4*>(vis_list), vis_counts, (uint2*)nullptr, 0.f);
   GS_CHECK_LAUNCH();
   return GS_OK;
 }
@@ -870,33 +1012,42 @@ extern "C" int gs_isect_bin_scatter(int32_t C, int32_t N, int32_t tile_w, int32_
   if (N == 0) return GS_OK;
   if (!splats || !tiles_per_gauss || !table || !isect_offsets || !pairs) return GS_ERR_INVALID_ARG;
   const int T = tile_w * tile_h;
-  hipLaunchKernelGGL((gs::isect_bin_kernel<true>), dim3((unsigned)n_slices, (unsigned)C), dim3(gs::BIN_THREADS),
+  hipLaunchKernelGGL((gs::isect_bin_kernel<true, false>), dim3((unsigned)n_slices, (unsigned)C), dim3(gs::BIN_THREADS),
                      (size_t)T * sizeof(uint32_t), (hipStream_t)stream, N, tile_w, T, n_slices,
                      bin_slice_rows(N, n_slices), splats, tiles_per_gauss, const_cast<uint32_t*>(table), isect_offsets,
-                     reinterpret_cast<uint2*>(pairs), (uint4*)nullptr, (int32_t*)nullptr);
+                     reinterpret_cast<uint2*>(pairs), (uint4*)nullptr, (int32_t*)nullptr, (uint2*)nullptr, 0.f);
   GS_CHECK_LAUNCH();
   return GS_OK;
 }
 
 extern "C" int gs_isect_bin_scatter_regions(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, int32_t n_slices,
                                             int32_t slices_per_group, int32_t n_regions, const uint64_t* vis_list,
-                                            const int32_t* vis_counts, const uint32_t* table,
-                                            const int32_t* isect_offsets, uint64_t* pairs, void* stream) {
+                                            const int32_t* vis_counts, const uint64_t* vis_masks,
+                                            const uint32_t* table, const int32_t* isect_offsets, uint64_t* pairs,
+                                            void* stream) {
   int st = bin_check(C, N, tile_w, tile_h, n_slices);
   if (st != GS_OK) return st;
   if (slices_per_group < 1 || n_regions < 1 || n_regions > 65535) return GS_ERR_INVALID_ARG;
   if (N == 0) return GS_OK;
-  if (!vis_list || !vis_counts || !table || !isect_offsets || !pairs || ((uintptr_t)vis_list & 15))
+  if (!vis_list || !vis_counts || !table || !isect_offsets || !pairs || ((uintptr_t)vis_list & 15) ||
+      ((uintptr_t)vis_masks & 7))
     return GS_ERR_INVALID_ARG;
   const int T = tile_w * tile_h;
   const int groups = (int)gs::ceil_div(n_slices, slices_per_group);
   if ((int64_t)groups * n_regions > 0x7fffffff) return GS_ERR_UNSUPPORTED;
   const int band_rows = (int)gs::ceil_div(tile_h, n_regions) + 1;
-  hipLaunchKernelGGL(gs::isect_region_scatter_kernel, dim3((unsigned)(groups * n_regions), (unsigned)C),
-                     dim3(gs::BIN_THREADS), (size_t)band_rows * tile_w * sizeof(uint32_t), (hipStream_t)stream, tile_w,
-                     tile_h, T, n_slices, slices_per_group, n_regions, bin_slice_rows(N, n_slices),
-                     reinterpret_cast<const uint4*>(vis_list), vis_counts, table, isect_offsets,
-                     reinterpret_cast<uint2*>(pairs));
+  const dim3 grid((unsigned)(groups * n_regions), (unsigned)C);
+  const size_t lds = (size_t)band_rows * tile_w * sizeof(uint32_t);
+  if (vis_masks)
+    hipLaunchKernelGGL(gs::isect_region_scatter_kernel<true>, grid, dim3(gs::BIN_THREADS), lds, (hipStream_t)stream,
+                       tile_w, tile_h, T, n_slices, slices_per_group, n_regions, bin_slice_rows(N, n_slices),
+                       reinterpret_cast<const uint4*>(vis_list), vis_counts, reinterpret_cast<const uint2*>(vis_masks),
+                       table, isect_offsets, reinterpret_cast<uint2*>(pairs));
+  else
+    hipLaunchKernelGGL(gs::isect_region_scatter_kernel<false>, grid, dim3(gs::BIN_THREADS), lds, (hipStream_t)stream,
+                       tile_w, tile_h, T, n_slices, slices_per_group, n_regions, bin_slice_rows(N, n_slices),
+                       reinterpret_cast<const uint4*>(vis_list), vis_counts, (const uint2*)nullptr, table,
+                       isect_offsets, reinterpret_cast<uint2*>(pairs));
   GS_CHECK_LAUNCH();
   return GS_OK;
 }

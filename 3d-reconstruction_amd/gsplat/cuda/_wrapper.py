@@ -409,17 +409,24 @@ class FrontSort:
 
 
 REGION_SCATTER = True  # scatter from the count pass's visible lists by tile band (False: by row slice, from the records)
+# rasterization() builds CULLED tile lists when it renders with gradients or packed (gs_isect_bin_count, "Culled
+# lists"): pairs whose splat cannot reach alpha 1/255 anywhere on the tile are left out.  No rendered value or gradient
+# changes; meta["isect_ids" / "flatten_ids" / "isect_offsets"] are then produced on first read, in gsplat's exact form.
+CULL_LISTS = True
 
 
 def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int, tile_height: int,
-                       front: bool = False):
+                       front: bool = False, cull_tile_size: int = 0):
     """isect_tiles + sort + isect_offset_encode in one binned pipeline (include/gsplat_mi355x.h, "binned isect_tiles").
     Returns (isect_ids int64 [I] sorted, flatten_ids int32 [I], isect_offsets int32 [C,TH,TW], tile_order, front_sort),
     the first three bit-identical to `isect_tiles_from_splats(sort=True)` + `isect_offset_encode`; tile_order is the
     longest-list-first tile permutation (int32 [C*TH*TW], or None) that the per-tile kernels are launched in.
     front_sort is None unless front=True, when it is a `FrontSort`: only the leading entries of long tile lists are in
-    order until its `finalize()` runs."""
+    order until its `finalize()` runs.
+    cull_tile_size > 0 (the rasterizer's tile edge in pixels): the culled lists of include/gsplat_mi355x.h -- a subset
+    of gsplat's, each tile's list still in gsplat's order; the offsets describe the culled lists."""
     dev = B.require_gpu(splats, tiles_per_gauss)
+    assert not cull_tile_size or REGION_SCATTER, "culled lists need the region scatter"
     C, N = tiles_per_gauss.shape
     T = tile_width * tile_height
     lib, st = B.lib(), B.stream_handle(dev)
@@ -433,14 +440,17 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
     # of 1..32 bands x 1..32 slices per group at 5 x 1242x375 and 1 x 1920x1280: DESIGN.md section 6)
     regions = 2 if tile_height >= 2 else 1
     group = max(1, -(-(n_slices * C * regions) // 256))
-    vis_list = vis_cnt = None
+    vis_list = vis_cnt = vis_masks = None
     if REGION_SCATTER:
         seg = int(lib.gs_isect_bin_slice_rows(N, n_slices))
         vis_list = torch.empty(C * n_slices * seg, 2, device=dev, dtype=torch.int64)
         vis_cnt = torch.empty(C * n_slices, device=dev, dtype=torch.int32)
+        if cull_tile_size:
+            vis_masks = torch.empty(C * n_slices * seg, device=dev, dtype=torch.int64)
     with B.device_guard(dev), B.timed("gs_isect_bin_count", dev):
         B.check(lib.gs_isect_bin_count(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss), n_slices,
-                                       B.ptr(table), B.ptr(vis_list), B.ptr(vis_cnt), st), "gs_isect_bin_count")
+                                       B.ptr(table), B.ptr(vis_list), B.ptr(vis_cnt), B.ptr(vis_masks),
+                                       int(cull_tile_size), st), "gs_isect_bin_count")
     with B.device_guard(dev), B.timed("gs_isect_bin_offsets", dev):
         B.check(lib.gs_isect_bin_offsets(C, tile_width, tile_height, n_slices, B.ptr(table), B.ptr(counts),
                                          B.ptr(offsets), B.ptr(total), st), "gs_isect_bin_offsets")
@@ -460,8 +470,8 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
     with B.device_guard(dev), B.timed("gs_isect_bin_scatter", dev):
         if vis_list is not None:
             B.check(lib.gs_isect_bin_scatter_regions(C, N, tile_width, tile_height, n_slices, group, regions,
-                                                     B.ptr(vis_list), B.ptr(vis_cnt), B.ptr(table), B.ptr(offsets),
-                                                     B.ptr(pairs), st), "gs_isect_bin_scatter_regions")
+                                                     B.ptr(vis_list), B.ptr(vis_cnt), B.ptr(vis_masks), B.ptr(table),
+                                                     B.ptr(offsets), B.ptr(pairs), st), "gs_isect_bin_scatter_regions")
         else:
             B.check(lib.gs_isect_bin_scatter(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
                                              n_slices, B.ptr(table), B.ptr(offsets), B.ptr(pairs), st),
@@ -548,14 +558,15 @@ class _RasterizeSplats(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, splats, means2d, tiles_per_gauss, backgrounds, width, height, tile_size, channels, ed, absgrad,
-                packed_index):
+                packed_index, cull=False):
         dev = B.require_gpu(splats)
         C, N = tiles_per_gauss.shape
         TW, TH = math.ceil(width / tile_size), math.ceil(height / tile_size)
         fs = None
         if TW * TH <= int(B.lib().gs_isect_bin_max_tiles()):
-            isect_ids, flatten_ids, offsets, order, fs = isect_tiles_binned(splats, tiles_per_gauss, TW, TH,
-                                                                            front=FRONT_SORT)
+            isect_ids, flatten_ids, offsets, order, fs = isect_tiles_binned(
+                splats, tiles_per_gauss, TW, TH, front=FRONT_SORT,
+                cull_tile_size=tile_size if (cull and REGION_SCATTER) else 0)
         else:
             order = None
             isect_ids, flatten_ids = isect_tiles_from_splats(splats, tiles_per_gauss, TW, TH)
@@ -675,4 +686,4 @@ class _RasterizeSplats(torch.autograd.Function):
                 vc = vc.clone()
                 vc[..., -1] = vc[..., -1] / ra[..., 0].clamp(min=1e-10)
             v_bg = (vc * (1.0 - ra)).sum(dim=(1, 2))
-        return v_splats, v_means2d, None, v_bg, None, None, None, None, None, None, None
+        return v_splats, v_means2d, None, v_bg, None, None, None, None, None, None, None, None

@@ -36,6 +36,7 @@ class _Meta(dict):
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
         self._front_sort = None
+        self._lists = None
         self._thunks = {}  # key -> callable producing the value on first read (the key is present, holding None)
 
     def _complete(self, key=None):
@@ -279,10 +280,25 @@ def rasterization(
 
         if needs_grad:  # the packed means2d must be on the autograd path before the rasterizer runs
             hook, packed_index = pack()["means2d"], pack()["_index"]
+    # Culled tile lists (gs_isect_bin_count): whenever the lists are not kept for a re-render with other opacities (the
+    # eval cache's no-grad, non-packed calls keep gsplat's full lists: the cull depends on the opacities)
+    cull = (W.CULL_LISTS and W.REGION_SCATTER and not use_cache and N > 0
+            and TW * TH <= int(B.lib().gs_isect_bin_max_tiles()))
     render_colors, render_alphas, isect_ids, flatten_ids, isect_offsets, last_ids = W._RasterizeSplats.apply(
-        splats, hook, tiles_per_gauss, bg, width, height, tile_size, channels, ed, absgrad, packed_index)
+        splats, hook, tiles_per_gauss, bg, width, height, tile_size, channels, ed, absgrad, packed_index, cull)
     meta._front_sort = W.take_front_sort()
     state = W.take_raster_state()
+    meta._lists = state  # (splats, offsets, isect_ids, flatten_ids, tile_order, front_sort) the rasterizer ran on
+    exact = None
+    if cull:
+        # the rasterizer ran on culled lists; gsplat's own arrays are built if and when `meta` is asked for them
+        meta._front_sort = None
+
+        def exact(_memo={}):
+            if not _memo:
+                ids, fids, offs, _, _ = W.isect_tiles_binned(splats.detach(), tiles_per_gauss, TW, TH, front=False)
+                _memo.update({"isect_ids": ids, "flatten_ids": fids, "isect_offsets": offs})
+            return _memo
     if packed:
         # without gradients nothing upstream needs the CSR arrays: build them when `meta` is first asked for one
         for k in ("camera_ids", "gaussian_ids", "radii", "means2d", "depths", "conics", "opacities"):
@@ -298,11 +314,17 @@ def rasterization(
         "flatten_ids": flatten_ids, "isect_offsets": isect_offsets, "last_ids": last_ids,
         "width": width, "height": height, "tile_size": tile_size, "n_cameras": C,
     })
+    if exact is not None:
+        for k in ("isect_ids", "flatten_ids", "isect_offsets"):
+            meta[k] = None
+            meta._thunks[k] = (lambda k=k: exact()[k])
     if packed:
         # A.7: in packed mode flatten_ids index the packed rows (the rank of the dense row among the visible ones)
         fs = meta._front_sort
 
         def packed_flatten_ids():
+            if exact is not None:
+                return pack()["_cum"][exact()["flatten_ids"].long()].to(torch.int32)
             if fs is not None:
                 fs.finalize()
             return pack()["_cum"][flatten_ids.long()].to(torch.int32)

@@ -240,6 +240,8 @@ def main():
                          "every rank; 'dense' = one SUM all-reduce per parameter tensor")
     ap.add_argument("--sh-backward", choices=["default", "fused", "split"], default="default",
                     help="single-GPU route of the in-rasterization SH backward (gsplat.cuda._wrapper.SPLIT_SH_BACKWARD)")
+    ap.add_argument("--no-cull", action="store_true",
+                    help="A/B: gsplat's full tile lists instead of the culled ones (gsplat.cuda._wrapper.CULL_LISTS)")
     ap.add_argument("--dump-stacks-after", type=float, default=0.0,
                     help="debugging: print every thread's Python stack to stderr after this many seconds (a hung run)")
     args = ap.parse_args()
@@ -277,6 +279,8 @@ def main():
     from gsplat.distributed import GradientExchange
     from gsplat.rendering import rasterization
 
+    if args.no_cull:
+        Wm.CULL_LISTS = False
     if render:
         run_render(args, dev, rank, world)
         if world > 1:
@@ -431,6 +435,7 @@ def main():
                                        f"{exchange.bytes_sent // max(1, args.steps + args.warmup + 3 + (args.warmup == 0))} "
                                        "payload bytes contributed per rank and step")
                        if world > 1 else "single GPU",
+                       "tile_lists": "culled (alpha < 1/255 over the whole tile left out)" if Wm.CULL_LISTS else "gsplat's",
                        "sh_backward": "split" if (Wm.SPLIT_SH_BACKWARD or (world > 1 and exchange.packs_colours))
                        else "fused"},
             "roofline": roofline,

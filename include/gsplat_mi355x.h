@@ -237,11 +237,21 @@ int gs_isect_offset_encode(int64_t n_isects, const int64_t* isect_ids_sorted,
 int32_t gs_isect_bin_max_tiles(void);
 /* vis_list / vis_counts (both or neither): the count pass also leaves every slice's visible rows as 16-byte entries
  * {flat row id, tile box lo, tile box hi, depth bits} in vis_list [C][n_slices][gs_isect_bin_slice_rows(N, n_slices)]
- * (uint64 pairs, 16-byte aligned) and their number in vis_counts [C][n_slices], for gs_isect_bin_scatter_regions. */
+ * (uint64 pairs, 16-byte aligned) and their number in vis_counts [C][n_slices], for gs_isect_bin_scatter_regions.
+ *
+ * Culled lists (vis_masks != NULL, needs vis_list; tile_size = the rasterizer's tile edge in pixels): a (row, tile)
+ * pair is counted only if the splat can reach alpha >= 1/255 on some pixel centre of the tile -- the rasterizer's own
+ * conservative whole-tile test, so every pair dropped is one that each pixel of the tile would skip (Appendix A.5,
+ * `alpha < 1/255 -> continue`) and NO rendered value or gradient changes.  The tile lists are then a subset of gsplat's
+ * (tile_counts / isect_offsets / n_isects describe the culled lists; tiles_per_gauss stays the box count), each still
+ * in gsplat's (depth, row id) order.  The decision is taken once, by this pass: vis_masks [C][n_slices][slice_rows]
+ * (uint64) holds, for every visible-list entry whose box has at most 64 tiles, bit t = tile t of the box (row-major)
+ * takes the pair; larger boxes are not culled.  gs_isect_bin_scatter_regions must be given the same vis_masks.
+ * With vis_masks == NULL the pipeline is gsplat's, bit for bit (tile_size is ignored). */
 int32_t gs_isect_bin_slice_rows(int32_t N, int32_t n_slices);
 int gs_isect_bin_count(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, const float* splats,
                        const int32_t* tiles_per_gauss, int32_t n_slices, uint32_t* table, uint64_t* vis_list,
-                       int32_t* vis_counts, void* stream);
+                       int32_t* vis_counts, uint64_t* vis_masks, int32_t tile_size, void* stream);
 int gs_isect_bin_offsets(int32_t C, int32_t tile_w, int32_t tile_h, int32_t n_slices, uint32_t* table,
                          int32_t* tile_counts, int32_t* isect_offsets, int64_t* total, void* stream);
 int gs_isect_bin_scatter(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, const float* splats,
@@ -252,8 +262,8 @@ int gs_isect_bin_scatter(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, c
  * slices, so the runs it writes into a tile segment are slices_per_group * n_regions times as long. */
 int gs_isect_bin_scatter_regions(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, int32_t n_slices,
                                  int32_t slices_per_group, int32_t n_regions, const uint64_t* vis_list,
-                                 const int32_t* vis_counts, const uint32_t* table, const int32_t* isect_offsets,
-                                 uint64_t* pairs, void* stream);
+                                 const int32_t* vis_counts, const uint64_t* vis_masks /* or NULL: see above */,
+                                 const uint32_t* table, const int32_t* isect_offsets, uint64_t* pairs, void* stream);
 int gs_isect_tile_sort(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets, int64_t n_isects,
                        const int32_t* tile_order /* launch order from gs_raster_tile_order, or NULL */,
                        const int32_t* size_classes /* its size_classes output (device int32[3]), or NULL */,

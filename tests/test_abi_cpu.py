@@ -193,8 +193,9 @@ def test_entry_points_reject_bad_arguments_before_any_launch():
     assert L.gs_rigid_transform_fwd(10, 0, P, P, P, P, P, P, P, None) == INVALID    # no instances
     assert L.gs_rigid_transform_fwd(10, 3, P, P + 4, P, P, P, P, P, None) == INVALID  # misaligned quats
     too_many = L.gs_isect_bin_max_tiles() + 1
-    assert L.gs_isect_bin_count(1, 10, too_many, 1, P, P, 1, P, None, None, None) == UNSUPPORTED
-    assert L.gs_isect_bin_scatter_regions(1, 10, 4, 4, 1, 0, 2, P, P, P, P, P, None) == INVALID  # slices_per_group < 1
+    assert L.gs_isect_bin_count(1, 10, too_many, 1, P, P, 1, P, None, None, None, 0, None) == UNSUPPORTED
+    assert L.gs_isect_bin_count(1, 10, 4, 4, P, P, 1, P, None, None, P, 16, None) == INVALID  # tile masks without the lists
+    assert L.gs_isect_bin_scatter_regions(1, 10, 4, 4, 1, 0, 2, P, P, None, P, P, P, None) == INVALID  # slices_per_group < 1
     assert L.gs_densify_accumulate(0, 10, P, P, 16, 1.0, 1.0, 1.0, 0, P, P, P, None) == INVALID   # C < 1
     assert L.gs_exclusive_scan_workspace_bytes(1000) > 0
     for code, word in ((INVALID, b"invalid"), (UNSUPPORTED, b"unsupported"), (WORKSPACE, b"workspace")):

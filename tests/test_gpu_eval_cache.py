@@ -42,7 +42,8 @@ def _independent(p, opac, vm, Ks, W, H, **kw):
 def _same(a, b):
     (rc1, ra1, m1), (rc0, ra0, m0) = a, b
     assert torch.equal(rc1, rc0) and torch.equal(ra1, ra0)
-    assert torch.equal(m1["last_ids"], m0["last_ids"])
+    # (last_ids index the lists the rasterizer ran on: gsplat's full lists for a cached call, the culled ones for an
+    # independent call -- not comparable across the two; the images above are what they produce)
     assert torch.equal(m1["radii"], m0["radii"])
     vis = m0["radii"] > 0
     assert torch.equal(m1["opacities"][vis], m0["opacities"][vis])

@@ -94,10 +94,10 @@ def test_front_sort_renders_identically(gpu_device, opac, expect_redo):
             rc, ra, meta = rasterization(p["means"], p["quats"], p["scales"], p["opacities"], p["colors"], vm.to(dev),
                                          Ks.to(dev), Wd, Hd, near_plane=0.1, packed=False, render_mode="RGB+ED",
                                          absgrad=True, rasterize_mode="antialiased")
-            fs = meta._front_sort
+            fs = meta._lists[5]  # the lists the rasterizer ran on (culled; meta[...] hands out gsplat's exact arrays)
             stats = None
             if fs is not None:
-                off = meta["isect_offsets"].reshape(-1).long()
+                off = meta._lists[1].reshape(-1).long()
                 n = torch.diff(torch.cat([off, torch.tensor([fs.isect_ids.numel()], device=dev)]))
                 stats = (int((fs.sorted_counts < n).sum()), int(fs.redo_flags[:-1].sum()), int((n > 1024).sum()))
             ((rc * wc).sum() + (ra * wa).sum()).backward()
