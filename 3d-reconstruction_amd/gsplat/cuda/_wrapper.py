@@ -377,10 +377,12 @@ class FrontSort:
     """State of a front-sorted intersection list (gs_isect_tile_sort_front): what is needed to sort the tiles the
     rasterizer flags (`redo`) and to complete every tile when the caller reads the arrays (`finalize`)."""
 
-    def __init__(self, geom, offsets, order, n_long, pairs, isect_ids, flatten_ids, sorted_counts):
+    def __init__(self, geom, offsets, order, n_long, pairs, isect_ids, flatten_ids, sorted_counts, redo_flags=None):
         self.geom, self.offsets, self.order, self.n_long = geom, offsets, order, n_long
         self.pairs, self.isect_ids, self.flatten_ids, self.sorted_counts = pairs, isect_ids, flatten_ids, sorted_counts
-        self.redo_flags = torch.zeros(sorted_counts.numel() + 1, device=sorted_counts.device, dtype=torch.int32)
+        if redo_flags is None:  # (the composite prepare call zeroes the one it is given)
+            redo_flags = torch.zeros(sorted_counts.numel() + 1, device=sorted_counts.device, dtype=torch.int32)
+        self.redo_flags = redo_flags
         self.complete = False
 
     def redo(self) -> None:
@@ -408,11 +410,41 @@ class FrontSort:
         self.pairs = None  # (stream-ordered: the allocator reuses it only behind the sort)
 
 
+_ISECT_LABELS = ("gs_isect_bin_count", "gs_isect_bin_offsets", "gs_raster_tile_order", "gs_isect_bin_scatter",
+                 "gs_isect_tile_sort")
+_RASTER_FWD_LABELS = ("gs_rasterize_fwd", "gs_rasterize_fwd_redo", "gs_isect_tile_sort_redo")
+_host_scalars = {}
+
+
+def _host_scalar() -> Tensor:
+    """A pinned int64 the composite prepare call writes n_isects into (one per thread: the call synchronises before it
+    returns, so the value is consumed before the next call can overwrite it)."""
+    import threading
+
+    key = threading.get_ident()
+    t = _host_scalars.get(key)
+    if t is None:
+        t = _host_scalars[key] = torch.zeros(1, dtype=torch.int64).pin_memory()
+    return t
+
+
+_bin_max_tiles = []
+
+
+def bin_max_tiles() -> int:
+    """Tiles per camera the binned pipeline takes (gs_isect_bin_max_tiles; constant of the library)."""
+    if not _bin_max_tiles:
+        _bin_max_tiles.append(int(B.lib().gs_isect_bin_max_tiles()))
+    return _bin_max_tiles[0]
+
+
 REGION_SCATTER = True  # scatter from the count pass's visible lists by tile band (False: by row slice, from the records)
 # rasterization() builds CULLED tile lists when it renders with gradients or packed (gs_isect_bin_count, "Culled
 # lists"): pairs whose splat cannot reach alpha 1/255 anywhere on the tile are left out.  No rendered value or gradient
 # changes; meta["isect_ids" / "flatten_ids" / "isect_offsets"] are then produced on first read, in gsplat's exact form.
 CULL_LISTS = True
+# gradient records up to this size are cleared on the main stream; larger ones on the side stream, behind the forward
+SIDE_STREAM_MIN_BYTES = 32 << 20
 
 
 def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int, tile_height: int,
@@ -447,26 +479,56 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
         vis_cnt = torch.empty(C * n_slices, device=dev, dtype=torch.int32)
         if cull_tile_size:
             vis_masks = torch.empty(C * n_slices * seg, device=dev, dtype=torch.int64)
-    with B.device_guard(dev), B.timed("gs_isect_bin_count", dev):
-        B.check(lib.gs_isect_bin_count(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss), n_slices,
-                                       B.ptr(table), B.ptr(vis_list), B.ptr(vis_cnt), B.ptr(vis_masks),
-                                       int(cull_tile_size), st), "gs_isect_bin_count")
-    with B.device_guard(dev), B.timed("gs_isect_bin_offsets", dev):
-        B.check(lib.gs_isect_bin_offsets(C, tile_width, tile_height, n_slices, B.ptr(table), B.ptr(counts),
-                                         B.ptr(offsets), B.ptr(total), st), "gs_isect_bin_offsets")
-    order = n_long = None
-    if C * T <= 131072:
+    want_order = C * T <= 131072
+    use_front = front and want_order
+    fused = REGION_SCATTER and not any(B.profiling_active(k) for k in _ISECT_LABELS)
+    order = n_long = redo_flags = None
+    if want_order:
         order = torch.empty(C * T, device=dev, dtype=torch.int32)
         n_long = torch.empty(3, device=dev, dtype=torch.int32)  # size classes of the order
-        with B.device_guard(dev), B.timed("gs_raster_tile_order", dev):
-            B.check(lib.gs_raster_tile_order(C * T, None, 0, B.ptr(counts), B.ptr(order), B.ptr(n_long), st),
-                    "gs_raster_tile_order")
-    n_isects = int(total.item())  # the one host sync of the pipeline (gsplat has the same one)
+    if fused:
+        # one FFI call: count + offsets + tile order + the host read of n_isects (include/gsplat_mi355x.h, "composite
+        # launches")
+        if use_front:
+            redo_flags = torch.empty(C * T + 1, device=dev, dtype=torch.int32)
+        host_n = _host_scalar()
+        with B.device_guard(dev):
+            B.check(lib.gs_isect_bin_prepare(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
+                                             n_slices, B.ptr(table), B.ptr(vis_list), B.ptr(vis_cnt), B.ptr(vis_masks),
+                                             int(cull_tile_size), B.ptr(counts), B.ptr(offsets), B.ptr(total),
+                                             B.ptr(order), B.ptr(n_long), B.ptr(redo_flags), host_n.data_ptr(), st),
+                    "gs_isect_bin_prepare")
+        n_isects = int(host_n[0])
+    else:
+        with B.device_guard(dev), B.timed("gs_isect_bin_count", dev):
+            B.check(lib.gs_isect_bin_count(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
+                                           n_slices, B.ptr(table), B.ptr(vis_list), B.ptr(vis_cnt), B.ptr(vis_masks),
+                                           int(cull_tile_size), st), "gs_isect_bin_count")
+        with B.device_guard(dev), B.timed("gs_isect_bin_offsets", dev):
+            B.check(lib.gs_isect_bin_offsets(C, tile_width, tile_height, n_slices, B.ptr(table), B.ptr(counts),
+                                             B.ptr(offsets), B.ptr(total), st), "gs_isect_bin_offsets")
+        if want_order:
+            with B.device_guard(dev), B.timed("gs_raster_tile_order", dev):
+                B.check(lib.gs_raster_tile_order(C * T, None, 0, B.ptr(counts), B.ptr(order), B.ptr(n_long), st),
+                        "gs_raster_tile_order")
+        n_isects = int(total.item())  # the one host sync of the pipeline (gsplat has the same one)
     isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64)
     flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
     if n_isects == 0:
         return isect_ids, flatten_ids, offsets, None, None
     pairs = torch.empty(n_isects, device=dev, dtype=torch.int64)
+    if fused:
+        with B.device_guard(dev):
+            B.check(lib.gs_isect_bin_build(C, N, tile_width, tile_height, n_slices, group, regions, B.ptr(vis_list),
+                                           B.ptr(vis_cnt), B.ptr(vis_masks), B.ptr(table), B.ptr(offsets), n_isects,
+                                           B.ptr(order), B.ptr(n_long), FRONT_K_TARGET if use_front else 0,
+                                           B.ptr(pairs), B.ptr(isect_ids), B.ptr(flatten_ids), B.ptr(counts), st),
+                    "gs_isect_bin_build")
+        if use_front:
+            fs = FrontSort((C, tile_width, tile_height), offsets, order, n_long, pairs, isect_ids, flatten_ids, counts,
+                           redo_flags)
+            return isect_ids, flatten_ids, offsets, order, fs
+        return isect_ids, flatten_ids, offsets, order, None
     with B.device_guard(dev), B.timed("gs_isect_bin_scatter", dev):
         if vis_list is not None:
             B.check(lib.gs_isect_bin_scatter_regions(C, N, tile_width, tile_height, n_slices, group, regions,
@@ -476,7 +538,7 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
             B.check(lib.gs_isect_bin_scatter(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
                                              n_slices, B.ptr(table), B.ptr(offsets), B.ptr(pairs), st),
                     "gs_isect_bin_scatter")
-    if front and order is not None:
+    if use_front:
         # `counts` (the list lengths) becomes sorted_counts: the front kernel overwrites the long tiles' entries
         with B.device_guard(dev), B.timed("gs_isect_tile_sort", dev):
             B.check(lib.gs_isect_tile_sort_front(C, tile_width, tile_height, B.ptr(offsets), n_isects, B.ptr(order),
@@ -520,6 +582,17 @@ def launch_raster_fwd(splats, offsets, flatten_ids, order, fs, bg, geom, rc, ra,
                                              B.ptr(opac_override), N, B.ptr(final_T), B.stream_handle(dev)),
                     "gs_rasterize_fwd")
 
+    if fs is not None and not any(B.profiling_active(k) for k in _RASTER_FWD_LABELS):
+        # pass 0 + redo sort + pass 1 in one FFI call
+        with B.device_guard(dev):
+            B.check(B.lib().gs_rasterize_fwd_front(C, width, height, tile_size, channels, B.ptr(splats), B.ptr(offsets),
+                                                   B.ptr(flatten_ids), n_isects, B.ptr(bg), int(ed), B.ptr(rc),
+                                                   B.ptr(ra), B.ptr(last_ids), B.ptr(order), B.ptr(work),
+                                                   B.ptr(fs.sorted_counts), B.ptr(fs.redo_flags), B.ptr(opac_override),
+                                                   N, B.ptr(final_T), B.ptr(fs.n_long), B.ptr(fs.pairs),
+                                                   B.ptr(fs.isect_ids), B.stream_handle(dev)),
+                    "gs_rasterize_fwd_front")
+        return
     raster(0)
     if fs is not None:
         # tiles whose pixels were still live at the end of their sorted front: sort those lists whole and rasterize
@@ -563,7 +636,7 @@ class _RasterizeSplats(torch.autograd.Function):
         C, N = tiles_per_gauss.shape
         TW, TH = math.ceil(width / tile_size), math.ceil(height / tile_size)
         fs = None
-        if TW * TH <= int(B.lib().gs_isect_bin_max_tiles()):
+        if TW * TH <= bin_max_tiles():
             isect_ids, flatten_ids, offsets, order, fs = isect_tiles_binned(
                 splats, tiles_per_gauss, TW, TH, front=FRONT_SORT,
                 cull_tile_size=tile_size if (cull and REGION_SCATTER) else 0)
@@ -580,17 +653,24 @@ class _RasterizeSplats(torch.autograd.Function):
         if ctx.needs_input_grad[0] and n_isects > 0:
             # the backward accumulates atomically into a zeroed gradient record; zero it now on a side stream, where
             # the HBM-bound fill hides behind the issue-bound forward rasterizer
-            main, side = torch.cuda.current_stream(dev), B.side_stream(dev)
             ctx.v_splats = torch.empty_like(splats)
-            side.wait_stream(main)
-            with B.device_guard(dev):  # (raw stream handle: no torch stream-context switch on the host)
-                B.check(B.lib().gs_fill_zero(B.ptr(ctx.v_splats), ctx.v_splats.numel() * 4, side.cuda_stream),
-                        "gs_fill_zero")
-            ctx.v_ready = torch.cuda.Event()
-            ctx.v_ready.record(side)
-            # written on the side stream: if the graph is dropped without a backward, the allocator must not hand
-            # the block to a main-stream tensor while the fill is still pending
-            ctx.v_splats.record_stream(side)
+            if ctx.v_splats.numel() * 4 <= SIDE_STREAM_MIN_BYTES:
+                # small record: the fill is a few microseconds of GPU time; the stream hand-over (two events, two
+                # waits) would cost the host more than that
+                with B.device_guard(dev):
+                    B.check(B.lib().gs_fill_zero(B.ptr(ctx.v_splats), ctx.v_splats.numel() * 4, B.stream_handle(dev)),
+                            "gs_fill_zero")
+            else:
+                main, side = torch.cuda.current_stream(dev), B.side_stream(dev)
+                side.wait_stream(main)
+                with B.device_guard(dev):  # (raw stream handle: no torch stream-context switch on the host)
+                    B.check(B.lib().gs_fill_zero(B.ptr(ctx.v_splats), ctx.v_splats.numel() * 4, side.cuda_stream),
+                            "gs_fill_zero")
+                ctx.v_ready = torch.cuda.Event()
+                ctx.v_ready.record(side)
+                # written on the side stream: if the graph is dropped without a backward, the allocator must not hand
+                # the block to a main-stream tensor while the fill is still pending
+                ctx.v_splats.record_stream(side)
         # longest-first tile schedule: by list length now, by the walked length (written by the forward) for backward
         n_tiles = C * TH * TW
         work = None
@@ -656,7 +736,8 @@ class _RasterizeSplats(torch.autograd.Function):
         v_ra = B.f32c(v_ra) if v_ra is not None else torch.zeros_like(ra)
         if ctx.v_splats is not None:
             v_splats, ctx.v_splats = ctx.v_splats, None  # single use (a second backward allocates afresh)
-            torch.cuda.current_stream(dev).wait_event(ctx.v_ready)
+            if ctx.v_ready is not None:
+                torch.cuda.current_stream(dev).wait_event(ctx.v_ready)
         else:
             v_splats = torch.zeros_like(splats)
         with B.device_guard(dev), B.timed("gs_rasterize_bwd", dev):

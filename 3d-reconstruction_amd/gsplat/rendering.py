@@ -283,7 +283,7 @@ def rasterization(
     # Culled tile lists (gs_isect_bin_count): whenever the lists are not kept for a re-render with other opacities (the
     # eval cache's no-grad, non-packed calls keep gsplat's full lists: the cull depends on the opacities)
     cull = (W.CULL_LISTS and W.REGION_SCATTER and not use_cache and N > 0
-            and TW * TH <= int(B.lib().gs_isect_bin_max_tiles()))
+            and TW * TH <= W.bin_max_tiles())
     render_colors, render_alphas, isect_ids, flatten_ids, isect_offsets, last_ids = W._RasterizeSplats.apply(
         splats, hook, tiles_per_gauss, bg, width, height, tile_size, channels, ed, absgrad, packed_index, cull)
     meta._front_sort = W.take_front_sort()

@@ -341,6 +341,35 @@ int gs_raster_tile_order(int32_t n_tiles, const int32_t* isect_offsets, int64_t 
                                                   the order is class-major, so these delimit contiguous ranges */,
                          void* stream);
 
+/* ---- composite launches (no reference counterpart: gsplat's Python layer issues its kernels one by one) ----------
+ * Fixed launch sequences of the binned pipeline in one call each, for hosts whose per-call cost matters (the Python
+ * layer on launch-bound shapes).  Same kernels, same order, same stream as the individual entry points above; every
+ * argument means what it means there.
+ *   gs_isect_bin_prepare   = gs_isect_bin_count + gs_isect_bin_offsets + gs_raster_tile_order (by tile_counts; skipped
+ *                            if tile_order == NULL) + zeroing of redo_flags [C*tile_h*tile_w + 1] (skipped if NULL), then
+ *                            copies `total` to *n_isects_host and SYNCHRONISES the stream: on return *n_isects_host is
+ *                            valid (the pipeline's one host synchronisation; pinned memory avoids a staging copy).
+ *   gs_isect_bin_build     = gs_isect_bin_scatter_regions + gs_isect_tile_sort_front (k_target > 0) or
+ *                            gs_isect_tile_sort (k_target == 0; sorted_counts unused).
+ *   gs_rasterize_fwd_front = gs_rasterize_fwd pass 0 + gs_isect_tile_sort_redo + gs_rasterize_fwd pass 1.             */
+int gs_isect_bin_prepare(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, const float* splats,
+                         const int32_t* tiles_per_gauss, int32_t n_slices, uint32_t* table, uint64_t* vis_list,
+                         int32_t* vis_counts, uint64_t* vis_masks, int32_t tile_size, int32_t* tile_counts,
+                         int32_t* isect_offsets, int64_t* total, int32_t* tile_order, int32_t* size_classes,
+                         int32_t* redo_flags, int64_t* n_isects_host, void* stream);
+int gs_isect_bin_build(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, int32_t n_slices,
+                       int32_t slices_per_group, int32_t n_regions, const uint64_t* vis_list, const int32_t* vis_counts,
+                       const uint64_t* vis_masks, const uint32_t* table, const int32_t* isect_offsets, int64_t n_isects,
+                       const int32_t* tile_order, const int32_t* size_classes, int32_t k_target, uint64_t* pairs,
+                       int64_t* isect_ids, int32_t* flatten_ids, int32_t* sorted_counts, void* stream);
+int gs_rasterize_fwd_front(int32_t C, int32_t width, int32_t height, int32_t tile_size, int32_t channels,
+                           const float* splats, const int32_t* isect_offsets, int32_t* flatten_ids, int64_t n_isects,
+                           const float* backgrounds, int32_t ed_last_channel, float* render_colors,
+                           float* render_alphas, int32_t* last_ids, const int32_t* tile_order, int32_t* tile_work,
+                           int32_t* sorted_counts, int32_t* redo_flags, const float* opacity_override,
+                           int32_t n_per_camera, float* final_T, const int32_t* size_classes, uint64_t* pairs,
+                           int64_t* isect_ids, void* stream);
+
 /* ---- packed mode ------------------------------------------------------------------------------ */
 /* Emits, in ascending (camera, gaussian) order, the rows with radii > 0. cum_excl = exclusive scan of
  * (radii > 0) computed with gs_exclusive_scan_i32 over `visible` (int32 0/1) written by gs_mark_visible. */
