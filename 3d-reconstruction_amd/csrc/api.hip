@@ -36,7 +36,8 @@ extern "C" int gs_isect_bin_prepare(int32_t C, int32_t N, int32_t tile_w, int32_
                                     const int32_t* tiles_per_gauss, int32_t n_slices, uint32_t* table,
                                     uint64_t* vis_list, int32_t* vis_counts, uint64_t* vis_masks, int32_t tile_size,
                                     int32_t* tile_counts, int32_t* isect_offsets, int64_t* total, int32_t* tile_order,
-                                    int32_t* size_classes, int32_t* redo_flags, int64_t* n_isects_host, void* stream) {
+                                    int32_t* size_classes, int32_t* redo_flags, int64_t* n_isects_host,
+                                    int32_t synchronize, void* stream) {
   if (!n_isects_host || !total) return GS_ERR_INVALID_ARG;
   int st = gs_isect_bin_count(C, N, tile_w, tile_h, splats, tiles_per_gauss, n_slices, table, vis_list, vis_counts,
                               vis_masks, tile_size, stream);
@@ -56,7 +57,13 @@ extern "C" int gs_isect_bin_prepare(int32_t C, int32_t N, int32_t tile_w, int32_
     e = hipMemsetAsync(redo_flags, 0, ((size_t)n_tiles + 1) * sizeof(int32_t), s);
     if (e != hipSuccess) return (int)e;
   }
+  if (!synchronize) return GS_OK;
   e = hipStreamSynchronize(s);
+  return e == hipSuccess ? GS_OK : (int)e;
+}
+
+extern "C" int gs_stream_synchronize(void* stream) {
+  const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
   return e == hipSuccess ? GS_OK : (int)e;
 }
 

@@ -428,6 +428,7 @@ def _host_scalar() -> Tensor:
     return t
 
 
+FUSED_LAUNCHES = True  # the composite entry points (one FFI call per launch sequence); False: one call per kernel
 _bin_max_tiles = []
 
 
@@ -448,7 +449,7 @@ SIDE_STREAM_MIN_BYTES = 32 << 20
 
 
 def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int, tile_height: int,
-                       front: bool = False, cull_tile_size: int = 0):
+                       front: bool = False, cull_tile_size: int = 0, while_counting=None):
     """isect_tiles + sort + isect_offset_encode in one binned pipeline (include/gsplat_mi355x.h, "binned isect_tiles").
     Returns (isect_ids int64 [I] sorted, flatten_ids int32 [I], isect_offsets int32 [C,TH,TW], tile_order, front_sort),
     the first three bit-identical to `isect_tiles_from_splats(sort=True)` + `isect_offset_encode`; tile_order is the
@@ -456,7 +457,9 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
     front_sort is None unless front=True, when it is a `FrontSort`: only the leading entries of long tile lists are in
     order until its `finalize()` runs.
     cull_tile_size > 0 (the rasterizer's tile edge in pixels): the culled lists of include/gsplat_mi355x.h -- a subset
-    of gsplat's, each tile's list still in gsplat's order; the offsets describe the culled lists."""
+    of gsplat's, each tile's list still in gsplat's order; the offsets describe the culled lists.
+    while_counting: a callable run after the count / offsets launches are queued and before the host waits for
+    n_isects -- host work (allocations, independent launches) placed there hides behind the GPU's first stage."""
     dev = B.require_gpu(splats, tiles_per_gauss)
     assert not cull_tile_size or REGION_SCATTER, "culled lists need the region scatter"
     C, N = tiles_per_gauss.shape
@@ -481,7 +484,7 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
             vis_masks = torch.empty(C * n_slices * seg, device=dev, dtype=torch.int64)
     want_order = C * T <= 131072
     use_front = front and want_order
-    fused = REGION_SCATTER and not any(B.profiling_active(k) for k in _ISECT_LABELS)
+    fused = FUSED_LAUNCHES and REGION_SCATTER and not any(B.profiling_active(k) for k in _ISECT_LABELS)
     order = n_long = redo_flags = None
     if want_order:
         order = torch.empty(C * T, device=dev, dtype=torch.int32)
@@ -496,8 +499,12 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
             B.check(lib.gs_isect_bin_prepare(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
                                              n_slices, B.ptr(table), B.ptr(vis_list), B.ptr(vis_cnt), B.ptr(vis_masks),
                                              int(cull_tile_size), B.ptr(counts), B.ptr(offsets), B.ptr(total),
-                                             B.ptr(order), B.ptr(n_long), B.ptr(redo_flags), host_n.data_ptr(), st),
+                                             B.ptr(order), B.ptr(n_long), B.ptr(redo_flags), host_n.data_ptr(), 0, st),
                     "gs_isect_bin_prepare")
+            if while_counting is not None:
+                while_counting()
+                while_counting = None
+            B.check(lib.gs_stream_synchronize(st), "gs_stream_synchronize")
         n_isects = int(host_n[0])
     else:
         with B.device_guard(dev), B.timed("gs_isect_bin_count", dev):
@@ -511,6 +518,8 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
             with B.device_guard(dev), B.timed("gs_raster_tile_order", dev):
                 B.check(lib.gs_raster_tile_order(C * T, None, 0, B.ptr(counts), B.ptr(order), B.ptr(n_long), st),
                         "gs_raster_tile_order")
+        if while_counting is not None:
+            while_counting()
         n_isects = int(total.item())  # the one host sync of the pipeline (gsplat has the same one)
     isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64)
     flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
@@ -582,7 +591,7 @@ def launch_raster_fwd(splats, offsets, flatten_ids, order, fs, bg, geom, rc, ra,
                                              B.ptr(opac_override), N, B.ptr(final_T), B.stream_handle(dev)),
                     "gs_rasterize_fwd")
 
-    if fs is not None and not any(B.profiling_active(k) for k in _RASTER_FWD_LABELS):
+    if fs is not None and FUSED_LAUNCHES and not any(B.profiling_active(k) for k in _RASTER_FWD_LABELS):
         # pass 0 + redo sort + pass 1 in one FFI call
         with B.device_guard(dev):
             B.check(B.lib().gs_rasterize_fwd_front(C, width, height, tile_size, channels, B.ptr(splats), B.ptr(offsets),
@@ -636,41 +645,52 @@ class _RasterizeSplats(torch.autograd.Function):
         C, N = tiles_per_gauss.shape
         TW, TH = math.ceil(width / tile_size), math.ceil(height / tile_size)
         fs = None
+        want_grad = ctx.needs_input_grad[0]
+        out = {}
+
+        def prepare_outputs():
+            # host work that does not depend on n_isects: run while the GPU is still counting (isect_tiles_binned)
+            out["rc"] = torch.empty(C, height, width, channels, device=dev, dtype=torch.float32)
+            out["ra"] = torch.empty(C, height, width, 1, device=dev, dtype=torch.float32)
+            out["last_ids"] = torch.empty(C, height, width, device=dev, dtype=torch.int32)
+            # the backward starts from each pixel's final transmittance: kept exactly, not re-derived from 1 - alpha
+            out["final_T"] = torch.empty(C, height, width, device=dev, dtype=torch.float32) if want_grad else None
+            out["v_splats"] = None
+            if want_grad:
+                # the backward accumulates atomically into a zeroed gradient record
+                out["v_splats"] = v = torch.empty_like(splats)
+                if v.numel() * 4 <= SIDE_STREAM_MIN_BYTES:
+                    # small record: the fill is a few microseconds of GPU time; the stream hand-over (two events, two
+                    # waits) would cost the host more than that
+                    with B.device_guard(dev):
+                        B.check(B.lib().gs_fill_zero(B.ptr(v), v.numel() * 4, B.stream_handle(dev)), "gs_fill_zero")
+
         if TW * TH <= bin_max_tiles():
             isect_ids, flatten_ids, offsets, order, fs = isect_tiles_binned(
                 splats, tiles_per_gauss, TW, TH, front=FRONT_SORT,
-                cull_tile_size=tile_size if (cull and REGION_SCATTER) else 0)
+                cull_tile_size=tile_size if (cull and REGION_SCATTER) else 0, while_counting=prepare_outputs)
         else:
             order = None
             isect_ids, flatten_ids = isect_tiles_from_splats(splats, tiles_per_gauss, TW, TH)
             offsets = isect_offset_encode(isect_ids, C, TW, TH)
+            prepare_outputs()
         bg = B.f32c(backgrounds) if backgrounds is not None else None
-        rc = torch.empty(C, height, width, channels, device=dev, dtype=torch.float32)
-        ra = torch.empty(C, height, width, 1, device=dev, dtype=torch.float32)
-        last_ids = torch.empty(C, height, width, device=dev, dtype=torch.int32)
+        rc, ra, last_ids, final_T = out["rc"], out["ra"], out["last_ids"], out["final_T"]
         n_isects = flatten_ids.numel()
-        ctx.v_splats = ctx.v_ready = None
-        if ctx.needs_input_grad[0] and n_isects > 0:
-            # the backward accumulates atomically into a zeroed gradient record; zero it now on a side stream, where
-            # the HBM-bound fill hides behind the issue-bound forward rasterizer
-            ctx.v_splats = torch.empty_like(splats)
-            if ctx.v_splats.numel() * 4 <= SIDE_STREAM_MIN_BYTES:
-                # small record: the fill is a few microseconds of GPU time; the stream hand-over (two events, two
-                # waits) would cost the host more than that
-                with B.device_guard(dev):
-                    B.check(B.lib().gs_fill_zero(B.ptr(ctx.v_splats), ctx.v_splats.numel() * 4, B.stream_handle(dev)),
-                            "gs_fill_zero")
-            else:
-                main, side = torch.cuda.current_stream(dev), B.side_stream(dev)
-                side.wait_stream(main)
-                with B.device_guard(dev):  # (raw stream handle: no torch stream-context switch on the host)
-                    B.check(B.lib().gs_fill_zero(B.ptr(ctx.v_splats), ctx.v_splats.numel() * 4, side.cuda_stream),
-                            "gs_fill_zero")
-                ctx.v_ready = torch.cuda.Event()
-                ctx.v_ready.record(side)
-                # written on the side stream: if the graph is dropped without a backward, the allocator must not hand
-                # the block to a main-stream tensor while the fill is still pending
-                ctx.v_splats.record_stream(side)
+        ctx.v_splats, ctx.v_ready = out["v_splats"], None
+        if ctx.v_splats is not None and ctx.v_splats.numel() * 4 > SIDE_STREAM_MIN_BYTES:
+            # large record: zero it on a side stream, where the HBM-bound fill hides behind the issue-bound forward
+            # rasterizer (issued here, behind the intersection stage: in front of it, it doubles the count pass)
+            main, side = torch.cuda.current_stream(dev), B.side_stream(dev)
+            side.wait_stream(main)
+            with B.device_guard(dev):  # (raw stream handle: no torch stream-context switch on the host)
+                B.check(B.lib().gs_fill_zero(B.ptr(ctx.v_splats), ctx.v_splats.numel() * 4, side.cuda_stream),
+                        "gs_fill_zero")
+            ctx.v_ready = torch.cuda.Event()
+            ctx.v_ready.record(side)
+            # written on the side stream: if the graph is dropped without a backward, the allocator must not hand
+            # the block to a main-stream tensor while the fill is still pending
+            ctx.v_splats.record_stream(side)
         # longest-first tile schedule: by list length now, by the walked length (written by the forward) for backward
         n_tiles = C * TH * TW
         work = None
@@ -683,8 +703,6 @@ class _RasterizeSplats(torch.autograd.Function):
             with B.device_guard(dev), B.timed("gs_raster_tile_order", dev):
                 B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, None, B.ptr(order), None,
                                                      B.stream_handle(dev)), "gs_raster_tile_order")
-        # the backward starts from each pixel's final transmittance: kept exactly, not re-derived from 1 - alpha
-        final_T = torch.empty(C, height, width, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         launch_raster_fwd(splats, offsets, flatten_ids, order, fs, bg, (C, N, width, height, tile_size, channels, ed),
                           rc, ra, last_ids, work, None, final_T)
         _tls.front_sort = fs

@@ -352,7 +352,9 @@ def main():
     if args.warmup == 0:
         meta = step()
     V = int((meta["radii"] > 0).sum().item())
-    I = int(meta["flatten_ids"].numel())
+    # gsplat's intersection count = the sum of the tile-box counts (what SURVEY.md 8(d)'s formulas are written in); the
+    # culled lists the rasterizer runs on are shorter, and asking `meta` for flatten_ids would build the full ones
+    I = int(meta["tiles_per_gauss"].sum().item())
     del meta
 
     def barrier():

@@ -347,8 +347,10 @@ int gs_raster_tile_order(int32_t n_tiles, const int32_t* isect_offsets, int64_t 
  * argument means what it means there.
  *   gs_isect_bin_prepare   = gs_isect_bin_count + gs_isect_bin_offsets + gs_raster_tile_order (by tile_counts; skipped
  *                            if tile_order == NULL) + zeroing of redo_flags [C*tile_h*tile_w + 1] (skipped if NULL), then
- *                            copies `total` to *n_isects_host and SYNCHRONISES the stream: on return *n_isects_host is
- *                            valid (the pipeline's one host synchronisation; pinned memory avoids a staging copy).
+ *                            copies `total` to *n_isects_host and, if `synchronize` != 0, SYNCHRONISES the stream: on
+ *                            return *n_isects_host is valid (the pipeline's one host synchronisation; pinned memory
+ *                            avoids a staging copy).  With synchronize == 0 the caller does its remaining host work
+ *                            first and then calls gs_stream_synchronize(stream) before reading *n_isects_host.
  *   gs_isect_bin_build     = gs_isect_bin_scatter_regions + gs_isect_tile_sort_front (k_target > 0) or
  *                            gs_isect_tile_sort (k_target == 0; sorted_counts unused).
  *   gs_rasterize_fwd_front = gs_rasterize_fwd pass 0 + gs_isect_tile_sort_redo + gs_rasterize_fwd pass 1.             */
@@ -356,7 +358,8 @@ int gs_isect_bin_prepare(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, c
                          const int32_t* tiles_per_gauss, int32_t n_slices, uint32_t* table, uint64_t* vis_list,
                          int32_t* vis_counts, uint64_t* vis_masks, int32_t tile_size, int32_t* tile_counts,
                          int32_t* isect_offsets, int64_t* total, int32_t* tile_order, int32_t* size_classes,
-                         int32_t* redo_flags, int64_t* n_isects_host, void* stream);
+                         int32_t* redo_flags, int64_t* n_isects_host, int32_t synchronize, void* stream);
+int gs_stream_synchronize(void* stream); /* hipStreamSynchronize */
 int gs_isect_bin_build(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, int32_t n_slices,
                        int32_t slices_per_group, int32_t n_regions, const uint64_t* vis_list, const int32_t* vis_counts,
                        const uint64_t* vis_masks, const uint32_t* table, const int32_t* isect_offsets, int64_t n_isects,

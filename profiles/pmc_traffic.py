@@ -28,8 +28,8 @@ from collections import defaultdict
 KERNELS = {  # bench.py entry-point label -> substring(s) of the HIP kernel names it launches
     "gs_projection_fwd": ["gs::projection_fwd_kernel"],
     "gs_projection_bwd": ["gs::projection_bwd_kernel", "gs::sh_bwd_packed_kernel"],
-    "gs_isect_bin_count": ["gs::isect_bin_kernel<false>"],
-    "gs_isect_bin_scatter": ["gs::isect_bin_kernel<true>", "gs::isect_region_scatter_kernel"],
+    "gs_isect_bin_count": ["gs::isect_bin_kernel<false, true>"],
+    "gs_isect_bin_scatter": ["gs::isect_region_scatter_kernel<true>"],
     "gs_isect_bin_offsets": ["gs::bin_slice_prefix_kernel", "gs::bin_offsets_kernel"],
     "gs_isect_tile_sort": ["gs::tile_sort_kernel", "gs::tile_sort_front_kernel"],
     "gs_rasterize_fwd": ["gs::rasterize_fwd_kernel"],
@@ -39,7 +39,7 @@ KERNELS = {  # bench.py entry-point label -> substring(s) of the HIP kernel name
 
 # entry points whose reads are mostly per-id gathers of 64-B splat records: label -> coalesced bytes per step that the
 # raw counter shows at half (filled in from the shape below)
-GATHER_DOMINATED = ("gs_rasterize_fwd", "gs_rasterize_bwd")
+GATHER_DOMINATED = ("gs_rasterize_fwd", "gs_rasterize_bwd", "gs_isect_bin_count")
 
 
 def per_kernel(directory, counter):
@@ -76,7 +76,9 @@ def main():
         if label in GATHER_DOMINATED:
             # coalesced streams of the kernel (128-B requests, shown at half): the backward's per-pixel inputs
             # (render_alphas, final_T, last_ids, v_colors [D], v_alphas); the id lists are a few % and left in the raw
-            stream = C * H * W * 4 * (D + 4) if label == "gs_rasterize_bwd" else 0
+            # (count pass: the [C,N] tile counts stream; everything else it reads is one 64-B record line per visible row,
+            # touched for the box and again, a few steps later, for the conic)
+            stream = {"gs_rasterize_bwd": C * H * W * 4 * (D + 4), "gs_isect_bin_count": C * N * 4}.get(label, 0)
             read = fetch * 1024 + stream / 2
             extra = {"read_bytes_upper": int(fetch * 1024 * 2),
                      "read_note": "gather-dominated: raw FETCH_SIZE (64-B requests are counted exactly) + half of the "
@@ -91,8 +93,10 @@ def main():
             expect = (2 * 4 * C * H * W * D + 2 * 4 * C * H * W) / 2
             out["calibration"]["read: rocblas dot, corrected/expected"] = round(v[1] * 2048 / expect, 3)
     for k, v in wr.items():
-        if "FillFunctor<float>" in k:
-            out["calibration"]["write: torch fill mean KiB per launch (raw)"] = round(v[1], 1)
+        if "fillBufferAligned" in k:  # the gradient record's hipMemsetAsync: C*N*64 bytes per step (+ a few small fills)
+            steps = max([c for kk, (c, _) in wr.items() if "gs::projection_fwd_kernel" in kk] or [1])
+            out["calibration"]["write: gradient-record memset, counted/expected"] = round(
+                v[1] * v[0] / steps * 1024 / (C * N * 64), 3)
     print(json.dumps(out, indent=1))
 
 

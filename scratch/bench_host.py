@@ -1,24 +1,35 @@
-"""Host-side cost of one rasterization() fwd+bwd: a scene so small that the GPU work is negligible."""
+"""Host-side cost of one rasterization() fwd+bwd: scenes so small that the GPU work is negligible, A/B in one process
+(box-to-box differences in host speed are larger than the effect): the round-1 host path (one FFI call per kernel,
+gradient record always cleared on the side stream, full tile lists) against the current one."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "3d-reconstruction_amd")]
 import torch
 import synth_scene
+import gsplat.cuda._wrapper as W
 from gsplat.rendering import rasterization
 dev = torch.device("cuda:0")
-for N, W, H in ((2000, 160, 96), (100_000, 310, 94), (1_000_000, 1242, 375)):
+MODES = {"one call per kernel, side-stream fill, full lists": (False, 0, False),
+         "composite calls, main-stream fill for small records, culled lists": (True, 32 << 20, True)}
+for N, Wd, H in ((2000, 160, 96), (100_000, 310, 94), (100_000, 1242, 375), (1_000_000, 1242, 375)):
     g = {k: v.to(dev).requires_grad_(True) for k, v in synth_scene.make_gaussians(N, sh_degree=None, extent=10.0).items()}
-    vm, Ks = (t.to(dev) for t in synth_scene.make_cameras(1, W, H))
+    vm, Ks = (t.to(dev) for t in synth_scene.make_cameras(1, Wd, H))
     def step():
         for v in g.values():
             v.grad = None
-        rc, ra, info = rasterization(g["means"], g["quats"], g["scales"], g["opacities"], g["colors"], vm, Ks, W, H,
+        rc, ra, info = rasterization(g["means"], g["quats"], g["scales"], g["opacities"], g["colors"], vm, Ks, Wd, H,
                                      near_plane=0.1, packed=False, absgrad=True, render_mode="RGB+ED")
         (rc.sum() + ra.sum()).backward()
-    for _ in range(5):
-        step()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(50):
-        step()
-    torch.cuda.synchronize()
-    print(f"N={N} {W}x{H}: {(time.perf_counter() - t0) / 50 * 1e3:.3f} ms per fwd+bwd (wall)")
+    res = {}
+    for rep in range(3):  # interleaved repetitions: min over them
+        for name, (fused, side_min, cull) in MODES.items():
+            W.FUSED_LAUNCHES, W.SIDE_STREAM_MIN_BYTES, W.CULL_LISTS = fused, side_min, cull
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(100):
+                step()
+            torch.cuda.synchronize()
+            res[name] = min(res.get(name, 1e9), (time.perf_counter() - t0) / 100 * 1e3)
+    for name, ms in res.items():
+        print(f"N={N} {Wd}x{H}: {ms:.3f} ms per fwd+bwd (wall)  [{name}]")
