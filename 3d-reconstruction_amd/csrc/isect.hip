@@ -58,7 +58,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(const int32_t
 
 // single workgroup: exclusive scan of block_sums in place, total -> *total_out
 __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(int64_t* __restrict__ block_sums, int64_t nb,
-                                                                       int64_t* __restrict__ total_out) {
+                                                                       int64_t* __restrict__ total_out,
+                                                                       int64_t tag = -1) {
   __shared__ int64_t sh[4];
   int64_t carry = 0;
   for (int64_t start = 0; start < nb; start += SCAN_THREADS) {
@@ -69,7 +70,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums_kernel(int64_t* 
     if (i < nb) block_sums[i] = carry + ex;
     carry += total;
   }
-  if (threadIdx.x == 0) *total_out = carry;
+  if (threadIdx.x == 0) {
+    *total_out = carry;
+    if (tag >= 0) total_out[1] = tag;  // gs_visibility_prefix: stat = {total, C}
+  }
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(const int32_t* __restrict__ in, int64_t n,
@@ -225,8 +229,36 @@ extern "C" int gs_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n,
   const int64_t nb = gs::ceil_div(n, gs::SCAN_TILE);
   int64_t* sums = (int64_t*)workspace;
   hipLaunchKernelGGL(gs::scan_reduce_kernel, dim3((unsigned)nb), dim3(gs::SCAN_THREADS), 0, s, in, n, sums);
-  hipLaunchKernelGGL(gs::scan_block_sums_kernel, dim3(1), dim3(gs::SCAN_THREADS), 0, s, sums, nb, total);
+  hipLaunchKernelGGL(gs::scan_block_sums_kernel, dim3(1), dim3(gs::SCAN_THREADS), 0, s, sums, nb, total,
+                     (int64_t)-1);
   hipLaunchKernelGGL(gs::scan_final_kernel, dim3((unsigned)nb), dim3(gs::SCAN_THREADS), 0, s, in, n, sums, out);
+  GS_CHECK_LAUNCH();
+  return GS_OK;
+}
+
+// Exclusive scan of the per-(camera, word) visible counts of gs_projection_fwd, and the two numbers that size the colour
+// message: stat[0] = visible pairs, stat[1] = C.  (gs_exclusive_scan_i32's three launches; a single-workgroup,
+// single-launch scan was measured at 59-155 us for the 78 k counts of configs[1] against 14 us for these three: one
+// CU's memory pipeline is the limit there.)
+extern "C" int gs_visibility_prefix(int32_t C, int32_t n_words, const int32_t* vis_counts, int32_t* vis_prefix,
+                                    int64_t* stat, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (C < 1 || n_words < 0 || !stat) return GS_ERR_INVALID_ARG;
+  const int64_t n = (int64_t)C * n_words;
+  if (n >= ((int64_t)1 << 31)) return GS_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    const int64_t host[2] = {0, C};
+    GS_HIP(hipMemcpyAsync(stat, host, sizeof(host), hipMemcpyHostToDevice, s));
+    return GS_OK;
+  }
+  if (!vis_counts || !vis_prefix || !workspace) return GS_ERR_INVALID_ARG;
+  if (workspace_bytes < gs_exclusive_scan_workspace_bytes(n)) return GS_ERR_WORKSPACE;
+  const int64_t nb = gs::ceil_div(n, gs::SCAN_TILE);
+  int64_t* sums = (int64_t*)workspace;
+  hipLaunchKernelGGL(gs::scan_reduce_kernel, dim3((unsigned)nb), dim3(gs::SCAN_THREADS), 0, s, vis_counts, n, sums);
+  hipLaunchKernelGGL(gs::scan_block_sums_kernel, dim3(1), dim3(gs::SCAN_THREADS), 0, s, sums, nb, stat, (int64_t)C);
+  hipLaunchKernelGGL(gs::scan_final_kernel, dim3((unsigned)nb), dim3(gs::SCAN_THREADS), 0, s, vis_counts, n, sums,
+                     vis_prefix);
   GS_CHECK_LAUNCH();
   return GS_OK;
 }

@@ -164,18 +164,32 @@ class _ProjectSplats(torch.autograd.Function):
                 B.ptr(covars), B.ptr(vis_words), B.ptr(vis_counts), B.stream_handle(dev)), "gs_projection_fwd")
         ctx.split = None
         if split:
-            vis_prefix, vis_total = exclusive_scan_i32(vis_counts)
             # the number of visible pairs sizes the message: to the host through pinned memory behind the scan, so
             # that reading it in backward costs no synchronisation of its own (the forward's n_isects read, later on
             # this stream, already covers it); with an exchange, the largest count over the ranks
             # ... and the largest camera count: every rank lays its message out alike
-            stat = torch.cat([vis_total, vis_total.new_full((1,), C)])
-            if exchange is not None:
-                stat = exchange.max_over_ranks(stat)
+            vis_prefix = torch.empty_like(vis_counts)
+            stat = torch.empty(2, device=dev, dtype=torch.int64)
+            wsb = int(B.lib().gs_exclusive_scan_workspace_bytes(C * n_words))
+            ws = torch.empty(max(wsb, 8), device=dev, dtype=torch.uint8)
+            with B.device_guard(dev), B.timed("gs_visibility_prefix", dev):
+                B.check(B.lib().gs_visibility_prefix(C, n_words, B.ptr(vis_counts), B.ptr(vis_prefix), B.ptr(stat),
+                                                     B.ptr(ws), wsb, B.stream_handle(dev)), "gs_visibility_prefix")
             host = torch.empty(2, dtype=torch.int64, pin_memory=True)
-            host.copy_(stat, non_blocking=True)
             ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(dev))
+            if exchange is not None:
+                # the MAX over the ranks and the copy to the host run on the side stream: nothing on the main stream
+                # (the whole intersection stage comes next) waits for the collective's latency
+                main, side = torch.cuda.current_stream(dev), B.side_stream(dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    stat_max = exchange.max_over_ranks(stat)
+                    host.copy_(stat_max, non_blocking=True)
+                    ready.record(side)
+                stat.record_stream(side)
+            else:
+                host.copy_(stat, non_blocking=True)
+                ready.record(torch.cuda.current_stream(dev))
             ctx.split = (vis_prefix, host, ready)
         ctx.exchange = exchange
         ctx.params = params
@@ -213,16 +227,27 @@ class _ProjectSplats(torch.autograd.Function):
         if not ok_layout:
             v_means2d = B.f32c(v_means2d)
         ld = v_means2d.stride(1) if N > 0 else 2
-        v_means = torch.empty_like(means)
-        v_quats = torch.empty_like(quats) if quats is not None else None
-        v_scales = torch.empty_like(scales) if scales is not None else None
+        ex = ctx.exchange
+        ctx.flat_geometry = None
+        if ex is not None and quats is not None and scales is not None and opacities.dim() == 1:
+            # one buffer for the four geometry gradients (sections padded to 256 B): ONE all-reduce instead of four
+            up = lambda n: (n + 63) // 64 * 64
+            o_m, o_s, o_o = up(4 * N), up(4 * N) + up(3 * N), up(4 * N) + 2 * up(3 * N)
+            flat = ctx.flat_geometry = torch.empty(o_o + up(N), device=dev, dtype=torch.float32)
+            v_quats = flat[:4 * N].view(N, 4)
+            v_means = flat[o_m:o_m + 3 * N].view(N, 3)
+            v_scales = flat[o_s:o_s + 3 * N].view(N, 3)
+            v_opac = flat[o_o:o_o + N]
+        else:
+            v_means = torch.empty_like(means)
+            v_quats = torch.empty_like(quats) if quats is not None else None
+            v_scales = torch.empty_like(scales) if scales is not None else None
+            v_opac = torch.empty_like(opacities)
         v_covars = torch.empty_like(covars) if covars is not None else None
-        v_opac = torch.empty_like(opacities)
         v_colors = torch.empty_like(colors) if colors is not None else None
         need_vm = ctx.needs_input_grad[5] or ctx.needs_input_grad[7]
         v_viewmats = torch.zeros(C, 4, 4, device=dev, dtype=torch.float32) if need_vm else None
         v_campos = torch.zeros(C, 3, device=dev, dtype=torch.float32) if (need_vm and campos is not None) else None
-        ex = ctx.exchange
         if ctx.split is not None:
             return _ProjectSplats._backward_split(ctx, means, quats, scales, opacities, colors, viewmats, Ks, campos,
                                                   radii, splats, v_splats, v_means2d, ld, v_means, v_quats, v_scales,
@@ -238,8 +263,9 @@ class _ProjectSplats(torch.autograd.Function):
             # dense exchange: SUM over the ranks of every Gaussian-parameter gradient.  Per-camera inputs (viewmats,
             # [C,N,D] colours) belong to this rank's cameras and stay local.
             shared_colours = v_colors if p.color_mode in (B.GS_COLOR_N, B.GS_COLOR_SH) else None
-            ex.all_reduce([t for t in (v_means, v_quats, v_scales, v_covars, v_opac, shared_colours)
-                           if t is not None]).wait()
+            geometry = ([ctx.flat_geometry] if ctx.flat_geometry is not None
+                        else [v_means, v_quats, v_scales, v_covars, v_opac])
+            ex.all_reduce([t for t in geometry + [shared_colours] if t is not None]).wait()
         g = ctx.needs_input_grad
         return (v_means if g[0] else None, v_quats if (g[1] and v_quats is not None) else None,
                 v_scales if (g[2] and v_scales is not None) else None,
@@ -270,7 +296,8 @@ class _ProjectSplats(torch.autograd.Function):
             # ONE all-gather of the messages (12 B per visible pair) instead of a 12 K-byte-per-Gaussian all-reduce of
             # v_sh; the geometry gradients (44 B per Gaussian) are SUM all-reduced behind it while the SH kernel runs
             msgs, n_msgs, local = ex.all_gather_messages(msg)
-            work = ex.all_reduce([v_means, v_quats, v_scales, v_opac])
+            work = ex.all_reduce([ctx.flat_geometry] if ctx.flat_geometry is not None
+                                 else [v_means, v_quats, v_scales, v_opac])
         v_means_sh = torch.empty_like(v_means) if ex is not None else v_means
         with B.device_guard(dev), B.timed("gs_sh_bwd_packed", dev):
             B.check(B.lib().gs_sh_bwd_packed(

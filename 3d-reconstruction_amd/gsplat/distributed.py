@@ -98,6 +98,9 @@ class GradientExchange:
         self.mode = "colour" if mode == "auto" else mode
         self.rank, self.world = world(group)
         self.active = self.world > 1 or force
+        # force: the exchange path, collectives included, runs even on one rank (tests: a one-rank RCCL group puts the
+        # real backend under every call the N-rank run makes)
+        self.collectives = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
         self._prev = None
         self.bytes_sent = 0  # payload bytes this rank contributed to collectives (diagnostics / tests)
 
@@ -123,7 +126,7 @@ class GradientExchange:
 
     # ---- collectives (called from the autograd nodes)
     def _nccl(self) -> bool:
-        return self.world > 1 and dist.get_backend(self.group) == "nccl"
+        return self.collectives and dist.get_backend(self.group) == "nccl"
 
     def _all_reduce(self, t: Tensor, op, async_op: bool):
         if t.is_cuda and not self._nccl():
@@ -137,7 +140,7 @@ class GradientExchange:
 
     def max_over_ranks(self, x: Tensor) -> Tensor:
         """MAX over the ranks of a small device tensor (the visible-pair count that sizes the messages)."""
-        if self.world == 1:
+        if not self.collectives:
             return x
         y = x.clone()
         self._all_reduce(y, dist.ReduceOp.MAX, False)
@@ -145,7 +148,7 @@ class GradientExchange:
 
     def all_reduce(self, tensors: Sequence[Tensor]) -> _Works:
         """Asynchronous in-place SUM of each tensor; returns a handle whose wait() orders the current stream behind."""
-        if self.world == 1:
+        if not self.collectives:
             return _Works([])
         works = []
         for t in tensors:
@@ -156,7 +159,7 @@ class GradientExchange:
     def all_gather_messages(self, msg: Tensor):
         """All-gather of one equally sized uint8 message per rank.  Returns (messages [world, len], world, own index);
         the current stream is ordered behind the collective."""
-        if self.world == 1:
+        if not self.collectives:
             return msg, 1, 0
         out = torch.empty(self.world, msg.numel(), device=msg.device, dtype=msg.dtype)
         self.bytes_sent += msg.numel()

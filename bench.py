@@ -175,6 +175,22 @@ def run_render(args, dev, rank, world):
               flush=True)
 
 
+class stdout_to_stderr:
+    """While RCCL starts (NCCL_DEBUG=VERSION is set on the GPU boxes: it prints its version banner on stdout), send
+    file descriptor 1 to stderr, so that this program's stdout carries the JSON line and nothing else."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def spawn_ranks(n: int) -> int:
     """Bare `python bench.py --gpus N` (no launcher): start the N ranks as fresh child processes of this, still
     GPU-free, process (nothing here has called into HIP: importing torch does not), one device per rank, rendezvous on
@@ -240,6 +256,9 @@ def main():
                          "every rank; 'dense' = one SUM all-reduce per parameter tensor")
     ap.add_argument("--sh-backward", choices=["default", "fused", "split"], default="default",
                     help="single-GPU route of the in-rasterization SH backward (gsplat.cuda._wrapper.SPLIT_SH_BACKWARD)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="N = 1 only: run the N-rank exchange path (split SH backward, packed messages, every collective) "
+                         "over a one-rank RCCL group -- what a rank of the N-GPU run computes, without the wire time")
     ap.add_argument("--no-cull", action="store_true",
                     help="A/B: gsplat's full tile lists instead of the culled ones (gsplat.cuda._wrapper.CULL_LISTS)")
     ap.add_argument("--dump-stacks-after", type=float, default=0.0,
@@ -270,9 +289,22 @@ def main():
         if args.rehearse_gloo:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            with stdout_to_stderr():
+                dist.init_process_group("nccl", device_id=dev)
+                dist.barrier()  # (communicator creation, and with it the banner, may be deferred to the first collective)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.force_exchange and world == 1:
+        import socket
+
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(s.getsockname()[1]))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            dist.barrier()
 
     from gsplat import _backend as B
     from gsplat.cuda import _wrapper as Wm
@@ -288,7 +320,7 @@ def main():
         return
     if args.sh_backward != "default":
         Wm.SPLIT_SH_BACKWARD = args.sh_backward == "split"
-    exchange = GradientExchange(mode=args.exchange)  # (a no-op context on one rank)
+    exchange = GradientExchange(mode=args.exchange, force=args.force_exchange)  # (a no-op context on one rank)
 
     N, C, W, H, K, D = args.gaussians, args.cams, args.width, args.height, 16, 4
     headline_shape = (N, C, W, H) == (1_000_000, 5, 1242, 375) and args.mode == "train"
@@ -436,9 +468,11 @@ def main():
                                        f"({'gloo REHEARSAL, not a result' if args.rehearse_gloo else 'RCCL'}), "
                                        f"{exchange.bytes_sent // max(1, args.steps + args.warmup + 3 + (args.warmup == 0))} "
                                        "payload bytes contributed per rank and step")
-                       if world > 1 else "single GPU",
+                       if world > 1 else ("single GPU" + (
+                           f", exchange path '{exchange.mode}' forced over a one-rank RCCL group (NOT the headline "
+                           "schedule)" if args.force_exchange else "")),
                        "tile_lists": "culled (alpha < 1/255 over the whole tile left out)" if Wm.CULL_LISTS else "gsplat's",
-                       "sh_backward": "split" if (Wm.SPLIT_SH_BACKWARD or (world > 1 and exchange.packs_colours))
+                       "sh_backward": "split" if (Wm.SPLIT_SH_BACKWARD or (exchange.active and exchange.packs_colours))
                        else "fused"},
             "roofline": roofline,
             "step_hbm_floor": {"algorithmic_bytes_per_step": total_bytes,
@@ -448,7 +482,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_threads)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -25,8 +25,9 @@
  * Conventions: every pointer is a DEVICE pointer unless its name ends in `_host`; all tensors are
  * dense row-major fp32 / int32 / int64 as stated; `stream` is a hipStream_t passed as void*.
  * Every function returns 0 on success, a positive hipError_t, or a negative GS_ERR_* code, and
- * never throws.  The library keeps no state between calls and never allocates device memory:
- * scratch space is passed in by the caller (sizes from the *_workspace_bytes functions).
+ * never throws.  The library never allocates device memory: scratch space is passed in by the caller
+ * (sizes from the *_workspace_bytes functions), and it keeps no state between calls -- with one
+ * stated exception, the static per-device scratch of gs_radix_sort_pairs_u64_u32_static.
  *
  * Splat record ("splats", 16 floats = 64 B per (camera, Gaussian), one HBM request per gather):
  *   [0] mean2d.x  [1] mean2d.y  [2] conic.a  [3] conic.b  [4] conic.c  [5] opacity*compensation
@@ -131,6 +132,12 @@ int gs_projection_bwd(const gs_proj_params* p,
  * gs_sh_bwd_packed turns n_msgs such messages, msg_stride bytes apart (this rank's own, or every rank's after ONE
  * all-gather), into v_sh [N,K,3] and the view-direction part of v_means, in a fixed order (bit-identical on every
  * rank).  cap >= number of visible pairs (rows beyond cap are dropped). */
+/* Exclusive scan of vis_counts [C][n_words] (gs_projection_fwd) -> vis_prefix [C][n_words] (the first packed row of
+ * every word, what gs_projection_bwd_split takes), and stat[0] = number of visible pairs, stat[1] = C (int64 device
+ * array of 2: what the ranks MAX-reduce to agree on `cap` and `layout_cams`).  Workspace as for
+ * gs_exclusive_scan_i32 over C * n_words elements. */
+int gs_visibility_prefix(int32_t C, int32_t n_words, const int32_t* vis_counts, int32_t* vis_prefix, int64_t* stat,
+                         void* workspace, int64_t workspace_bytes, void* stream);
 int gs_colour_message_layout(int32_t C, int32_t N, int64_t cap, int64_t* out5_host);
 int gs_projection_bwd_split(const gs_proj_params* p,
                             const float* means, const float* quats, const float* scales,

@@ -167,6 +167,75 @@ def test_two_ranks_equal_single_process(gpu_device, mode):
         assert got[0][1] < 0.5 * (N * 236)  # well under the dense exchange's 236 B per Gaussian
 
 
+# ------------------------------------------------------------------------------------------ one rank, the real backend
+def _rccl_main(port, mode, q):
+    for p_ in (ROOT, os.path.join(ROOT, "3d-reconstruction_amd"), os.path.join(ROOT, "tests")):
+        if p_ not in sys.path:
+            sys.path.insert(0, p_)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+
+    import synth_scene as S
+    from gsplat.distributed import GradientExchange, all_reduce_densification_stats, all_reduce_gradients
+    from gsplat.rendering import rasterization
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)  # as bench.py starts its ranks
+    N, C, W, H = 5000, 3, 160, 100
+    g = S.make_gaussians(N, sh_degree=3, extent=10.0, seed=21)
+    vm, Ks = S.make_cameras(C, W, H)
+    p = {k: v.to(dev).requires_grad_(True) for k, v in g.items()}
+    gen = torch.Generator().manual_seed(4)
+    wc = torch.randn(C, H, W, 4, generator=gen).to(dev)
+    wa = torch.randn(C, H, W, 1, generator=gen).to(dev)
+    ex = GradientExchange(mode=mode, force=True)
+    assert ex.collectives and ex._nccl()
+    for _ in range(2):  # twice: the second step reuses the communicator from the autograd thread
+        for v in p.values():
+            v.grad = None
+        with ex:
+            rc, ra, meta = rasterization(p["means"], p["quats"], p["scales"], p["opacities"], p["colors"], vm.to(dev),
+                                         Ks.to(dev), W, H, near_plane=0.1, sh_degree=3, packed=False,
+                                         render_mode="RGB+ED", absgrad=True, rasterize_mode="antialiased")
+        ((rc * wc).sum() + (ra * wa).sum()).backward()
+    grads = {k: v.grad.clone() for k, v in p.items()}
+    all_reduce_gradients(p.values())  # world 1: returns early, by contract
+    stats = [torch.ones(N, device=dev), torch.ones(N, device=dev), torch.ones(N, device=dev)]
+    all_reduce_densification_stats(*stats)
+    dist.barrier()
+    t = torch.tensor([1.5], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)  # bench.py's max-over-ranks timing
+    torch.cuda.synchronize()
+    q.put(({k: v.cpu() for k, v in grads.items()}, ex.bytes_sent, float(t.item())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["colour", "dense"])
+def test_exchange_over_a_one_rank_rccl_group(gpu_device, mode):
+    """The N-rank run's collectives (MAX all-reduce of the layout, all-gather of the uint8 messages, asynchronous
+    all-reduces issued from the autograd thread, the bench's barrier / float64 MAX) on the REAL backend: a one-rank RCCL
+    group with the exchange forced on.  Two ranks cannot share this box's single GPU under RCCL; what this pins is that
+    every call, dtype and thread context the 8-GPU run uses is accepted by RCCL and leaves the gradients unchanged."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31300 + (os.getpid() % 1500) + (0 if mode == "colour" else 1)
+    proc = ctx.Process(target=_rccl_main, args=(port, mode, q))
+    proc.start()
+    grads, sent, tmax = q.get(timeout=300)
+    proc.join(timeout=120)
+    assert proc.exitcode == 0
+    assert tmax == 1.5 and sent > 0
+    N, C, W, H = 5000, 3, 160, 100
+    g = synth_scene.make_gaussians(N, sh_degree=3, extent=10.0, seed=21)
+    vm, Ks = synth_scene.make_cameras(C, W, H)
+    ref = _grads(gpu_device, g, vm, Ks, W, H, 3, split=False, seed=4)
+    for k in ("means", "quats", "scales", "opacities", "colors"):
+        assert_close(f"rccl1.{mode}.v_{k}", grads[k], ref[k].cpu(), scale_atol=True, max_bad_frac=1e-4, max_rel_l2=1e-5)
+
+
 # ------------------------------------------------------------------------------------------ message format
 def test_colour_message_matches_reference_pack_and_multi_message_rebuild(gpu_device):
     """Through the C ABI: the visibility words / counts of gs_projection_fwd and the message gs_projection_bwd_split
