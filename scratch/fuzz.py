@@ -7,6 +7,9 @@ import torch
 import oracle, synth_scene
 from gsplat.rendering import rasterization
 dev = torch.device("cuda:0")
+if os.environ.get("FUZZ_NOCULL"):
+    import gsplat.cuda._wrapper as _W
+    _W.CULL_LISTS = False
 base_seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 only = int(sys.argv[3]) if len(sys.argv) > 3 else None
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
@@ -26,6 +29,7 @@ for case in range(n_cases):
     dense = rnd.random() < 0.3
     if only is not None and case != only:
         continue
+    mode = os.environ.get("FUZZ_MODE", mode)
     g = synth_scene.make_gaussians(N, sh_degree=sh, seed=case, extent=extent)
     if dense:
         g["scales"] = g["scales"] * 3.0
