@@ -945,6 +945,18 @@ static inline int bin_ilog2_floor(int64_t v) {
 
 }  // namespace gs
 
+#ifndef GS_TS_W2
+#define GS_TS_W2 4
+#endif
+#ifndef GS_TS_W3
+#define GS_TS_W3 2
+#endif
+#ifndef GS_TS_G2
+#define GS_TS_G2 16
+#endif
+#ifndef GS_TS_G3
+#define GS_TS_G3 14
+#endif
 static int bin_check(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, int32_t n_slices) {
   if (C < 1 || N < 0 || tile_w < 1 || tile_h < 1 || n_slices < 1) return GS_ERR_INVALID_ARG;
   if ((int64_t)tile_w * tile_h > gs::BIN_MAX_TILES) return GS_ERR_UNSUPPORTED;
@@ -1072,8 +1084,8 @@ extern "C" int gs_isect_tile_sort(int32_t C, int32_t tile_w, int32_t tile_h, con
     // classes run 4 / 2 waves per segment (one wave each left 8 waves per CU: 0.136 -> 0.110 ms for the chain)
     hipLaunchKernelGGL((gs::tile_sort_kernel<6144, 0, 16>), dim3(256), dim3(1024), 0, s, GS_TS_ARGS);
     hipLaunchKernelGGL((gs::tile_sort_kernel<2048, 1, 4>), dim3(256 * 3), dim3(256), 0, s, GS_TS_ARGS);
-    hipLaunchKernelGGL((gs::tile_sort_kernel<1024, 2, 4>), dim3(256 * 8), dim3(256), 0, s, GS_TS_ARGS);
-    hipLaunchKernelGGL((gs::tile_sort_kernel<512, 3, 2>), dim3(256 * 14), dim3(128), 0, s, GS_TS_ARGS);
+    hipLaunchKernelGGL((gs::tile_sort_kernel<1024, 2, GS_TS_W2>), dim3(256 * GS_TS_G2), dim3(64 * GS_TS_W2), 0, s, GS_TS_ARGS);
+    hipLaunchKernelGGL((gs::tile_sort_kernel<512, 3, GS_TS_W3>), dim3(256 * GS_TS_G3), dim3(64 * GS_TS_W3), 0, s, GS_TS_ARGS);
   } else {
     hipLaunchKernelGGL((gs::tile_sort_kernel<2048, -1, 4>), dim3((unsigned)n_tiles), dim3(256), 0, s, GS_TS_ARGS);
   }
@@ -1115,9 +1127,9 @@ extern "C" int gs_isect_tile_sort_front(int32_t C, int32_t tile_w, int32_t tile_
   hipLaunchKernelGGL((gs::tile_sort_kernel<2048, 1, 4>), dim3(256 * 3), dim3(256), 0, s, GS_TSF_ARGS,
                      (const int32_t*)sorted_counts, 0, sorted_counts);
   // short segments: sorted whole (sorted_counts was pre-filled with the list lengths by the caller)
-  hipLaunchKernelGGL((gs::tile_sort_kernel<1024, 2, 4>), dim3(256 * 8), dim3(256), 0, s, GS_TSF_ARGS,
+  hipLaunchKernelGGL((gs::tile_sort_kernel<1024, 2, GS_TS_W2>), dim3(256 * GS_TS_G2), dim3(64 * GS_TS_W2), 0, s, GS_TSF_ARGS,
                      (const int32_t*)nullptr, 0, (int32_t*)nullptr);
-  hipLaunchKernelGGL((gs::tile_sort_kernel<512, 3, 2>), dim3(256 * 14), dim3(128), 0, s, GS_TSF_ARGS,
+  hipLaunchKernelGGL((gs::tile_sort_kernel<512, 3, GS_TS_W3>), dim3(256 * GS_TS_G3), dim3(64 * GS_TS_W3), 0, s, GS_TSF_ARGS,
                      (const int32_t*)nullptr, 0, (int32_t*)nullptr);
   GS_CHECK_LAUNCH();
   return GS_OK;
