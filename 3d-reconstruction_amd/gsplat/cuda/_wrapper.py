@@ -455,6 +455,9 @@ def _host_scalar() -> Tensor:
     return t
 
 
+SLICES_TOTAL = 512        # count-pass workgroups over all cameras (row slices x cameras)
+SCATTER_REGIONS = 2       # bands of tile rows in the region scatter
+SCATTER_WORKGROUPS = 256  # ... and about this many scatter workgroups (slices are grouped to get there)
 FUSED_LAUNCHES = True  # the composite entry points (one FFI call per launch sequence); False: one call per kernel
 _bin_max_tiles = []
 
@@ -493,15 +496,15 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
     T = tile_width * tile_height
     lib, st = B.lib(), B.stream_handle(dev)
     # 1024-thread workgroups, two per CU over all cameras (fewer, longer slices keep the scatter's runs long)
-    n_slices = max(1, min(max(512 // C, 1), -(-max(N, 1) // 4096)))
+    n_slices = max(1, min(max(SLICES_TOTAL // C, 1), -(-max(N, 1) // 4096)))
     table = torch.empty(C * n_slices * T, device=dev, dtype=torch.int32)
     counts = torch.empty(C * T, device=dev, dtype=torch.int32)
     offsets = torch.empty(C, tile_height, tile_width, device=dev, dtype=torch.int32)
     total = torch.empty(1, device=dev, dtype=torch.int64)
     # region scatter: two bands of tile rows x groups of slices, about one 1024-thread workgroup per CU (measured best
     # of 1..32 bands x 1..32 slices per group at 5 x 1242x375 and 1 x 1920x1280: DESIGN.md section 6)
-    regions = 2 if tile_height >= 2 else 1
-    group = max(1, -(-(n_slices * C * regions) // 256))
+    regions = min(SCATTER_REGIONS, tile_height)
+    group = max(1, -(-(n_slices * C * regions) // SCATTER_WORKGROUPS))
     vis_list = vis_cnt = vis_masks = None
     if REGION_SCATTER:
         seg = int(lib.gs_isect_bin_slice_rows(N, n_slices))
