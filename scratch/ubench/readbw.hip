@@ -131,5 +131,51 @@ int main() {
   printf("per-lane 192-B rows, 4-B-aligned dwordx4/x3 mix: %.2f TB/s\n", bytes / mu / 1e9);
   double mrw = time_ms([&] { hipLaunchKernelGGL(rd_rows192_rw, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, 0, x, (const float*)y, (float*)y + rows * 3, rows); });
   printf("per-lane 192-B rows + 12 B read + 12 B write per row: %.2f TB/s of the rows' bytes\n", bytes / mrw / 1e9);
+  // the same row read at the standalone SH op's size (3 M rows = 576 MB), back to back and with another kernel's
+  // 1.2 GB of writes between launches (what the op sees inside a training step)
+  {
+    const size_t rows3 = 3000000;
+    double mb = time_ms([&] { hipLaunchKernelGGL(rd_rows192, dim3((unsigned)((rows3 + 255) / 256)), dim3(256), 0, 0, x, rows3, out); });
+    printf("per-lane 192-B rows, 3 M rows back to back: %.2f TB/s\n", rows3 * 192.0 / mb / 1e9);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    double tot = 0;
+    for (int i = 0; i < 10; ++i) {
+      hipLaunchKernelGGL(wr, dim3(4096), dim3(256), 0, 0, y, n4);
+      hipEventRecord(a);
+      hipLaunchKernelGGL(rd_rows192, dim3((unsigned)((rows3 + 255) / 256)), dim3(256), 0, 0, x, rows3, out);
+      hipEventRecord(b); hipEventSynchronize(b);
+      float ms; hipEventElapsedTime(&ms, a, b); tot += ms;
+    }
+    printf("per-lane 192-B rows, 3 M rows, a 1.2 GB write kernel between launches: %.2f TB/s\n", rows3 * 192.0 / (tot / 10) / 1e9);
+    // cold-context ceilings: one launch at a time, another kernel over a DIFFERENT 1.2 GB buffer in between
+    auto cold = [&](const char* what, auto flush, auto run, double bytes_moved) {
+      double t = 0;
+      for (int i = 0; i < 10; ++i) {
+        flush();
+        hipEventRecord(a);
+        run();
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b); t += ms;
+      }
+      printf("%s: %.2f TB/s\n", what, bytes_moved / (t / 10) / 1e9);
+    };
+    auto flush_w = [&] { hipLaunchKernelGGL(wr, dim3(4096), dim3(256), 0, 0, y, n4); };
+    auto flush_r = [&] { hipLaunchKernelGGL(rd<8>, dim3(4096), dim3(256), 0, 0, (const float4*)y, n4, out); };
+    const size_t n4s = rows3 * 12;
+    cold("coalesced read of 576 MB after a 1.2 GB write elsewhere", flush_w,
+         [&] { hipLaunchKernelGGL(rd<8>, dim3(8192), dim3(256), 0, 0, x, n4s, out); }, n4s * 16.0);
+    cold("coalesced read of 576 MB after a 1.2 GB read elsewhere", flush_r,
+         [&] { hipLaunchKernelGGL(rd<8>, dim3(8192), dim3(256), 0, 0, x, n4s, out); }, n4s * 16.0);
+    cold("per-lane 192-B rows, 3 M rows, after a 1.2 GB read elsewhere", flush_r,
+         [&] { hipLaunchKernelGGL(rd_rows192, dim3((unsigned)((rows3 + 255) / 256)), dim3(256), 0, 0, x, rows3, out); }, rows3 * 192.0);
+    cold("coalesced read of 1.2 GB after a 1.2 GB write elsewhere", flush_w,
+         [&] { hipLaunchKernelGGL(rd<8>, dim3(8192), dim3(256), 0, 0, x, n4, out); }, n4 * 16.0);
+    cold("write of 1.2 GB after a 1.2 GB read elsewhere", [&] { hipLaunchKernelGGL(rd<8>, dim3(4096), dim3(256), 0, 0, x, n4, out); },
+         [&] { hipLaunchKernelGGL(wr, dim3(8192), dim3(256), 0, 0, y, n4); }, n4 * 16.0);
+    for (size_t rr : {(size_t)1000000, (size_t)2000000, (size_t)4000000, (size_t)6000000}) {
+      double m = time_ms([&] { hipLaunchKernelGGL(rd_rows192, dim3((unsigned)((rr + 255) / 256)), dim3(256), 0, 0, x, rr, out); });
+      printf("per-lane 192-B rows, %zu rows back to back: %.2f TB/s (%.1f us)\n", rr, rr * 192.0 / m / 1e9, m * 1e3);
+    }
+  }
   return 0;
 }
