@@ -356,15 +356,18 @@ __global__ __launch_bounds__(64) void rasterize_bwd_kernel(
   if (slot == 2 || slot == 4) post = -0.5f;
   if (slot == 3) post = -1.f;
 
+  // a lane owns the same pixel of each of the tile's four 8x8 QUADRANTS (p = quadrant): a splat that reaches only some
+  // quadrants -- 2.7 of 4 on average -- skips the others' pixel work on a wave-uniform branch, where a 2x2 quad per
+  // lane would evaluate all 256 pixels for every splat
   const float x0 = (float)(tg.tx * 16) + 0.5f, y0 = (float)(tg.ty * 16) + 0.5f;
-  const int ix0 = tg.tx * 16 + 2 * (lane & 7), iy0 = tg.ty * 16 + 2 * (lane >> 3);
+  const int ix0 = tg.tx * 16 + (lane & 7), iy0 = tg.ty * 16 + (lane >> 3);
   const float px0 = (float)ix0 + 0.5f, py0 = (float)iy0 + 0.5f;
   float T[4], E[4], vo[4][CH];
   int last[4];
   int my_max = -1;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    const int x = ix0 + (p & 1), y = iy0 + (p >> 1);
+    const int x = ix0 + 8 * (p & 1), y = iy0 + 8 * (p >> 1);
     T[p] = 1.f; E[p] = 0.f; last[p] = -1;
 #pragma unroll
     for (int k = 0; k < CH; ++k) vo[p][k] = 0.f;
@@ -416,51 +419,57 @@ __global__ __launch_bounds__(64) void rasterize_bwd_kernel(
   if (k_top >= tg.start) prefetch(k_top);
   for (int kb = k_top; kb >= tg.start; kb -= 64) {
     const float A = CONIC_SCALE * n0.z, Bh = CONIC_SCALE * n0.w, Cc = CONIC_SCALE * n1.x;
-    const bool keep = (kb - lane >= tg.start) && rect_may_touch(n0.x, n0.y, A, Bh, Cc, n1.y, x0, y0, 15.f);
+    // exact cull against each quadrant (one lane per staged splat): the quadrants it may reach, as a 4-bit mask
+    unsigned qm = 0u;
+    if (kb - lane >= tg.start) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (rect_may_touch(n0.x, n0.y, A, Bh, Cc, n1.y, x0 + 8.f * (float)(q & 1), y0 + 8.f * (float)(q >> 1), 7.f))
+          qm |= 1u << q;
+    }
+    const bool keep = qm != 0u;
     const unsigned long long kmask = __ballot(keep);
     const int cnt = __popcll(kmask);
     if (keep) {
       const int pos = __popcll(kmask & lt_mask);
       sg[pos * 3 + 0] = make_float4(n0.x, n0.y, A, Bh);
       sg[pos * 3 + 1] = make_float4(Cc, n1.y, n1.z, n1.w);
-      sg[pos * 3 + 2] = make_float4(n2.x, n2.y, __int_as_float(kb - lane), __int_as_float(nid));
+      // (list index as its distance below kb: 6 bits; the quadrant mask above it)
+      sg[pos * 3 + 2] = make_float4(n2.x, n2.y, __int_as_float(lane | (int)(qm << 8)), __int_as_float(nid));
     }
     __syncthreads();
     if (kb - 64 >= tg.start) prefetch(kb - 64);
     for (int j = 0; j < cnt; ++j) {
       const float4 q0 = sg[j * 3 + 0];  // mx my A Bh
       const float4 q1 = sg[j * 3 + 1];  // C op c0 c1
-      const float4 q2 = sg[j * 3 + 2];  // c2 c3 k gid
-      const int k = __float_as_int(q2.z);
-      const float dx0 = q0.x - px0, dx1 = dx0 - 1.f;
-      const float dy0 = q0.y - py0, dy1 = dy0 - 1.f;
+      const float4 q2 = sg[j * 3 + 2];  // c2 c3 (k offset | quadrant mask) gid
+      const int meta = __builtin_amdgcn_readfirstlane(__float_as_int(q2.z));  // (every lane read the same slot)
+      const int k = kb - (meta & 63);
+      const unsigned quads = (unsigned)meta >> 8;
+      const float dx0 = q0.x - px0, dx1 = dx0 - 8.f;
+      const float dy0 = q0.y - py0, dy1 = dy0 - 8.f;
       const float adx[2] = {q0.z * dx0, q0.z * dx1}, bdx[2] = {q0.w * dx0, q0.w * dx1};
       const float bdy[2] = {q0.w * dy0, q0.w * dy1}, cdy[2] = {q1.x * dy0, q1.x * dy1};
       const float dxv[2] = {dx0, dx1}, dyv[2] = {dy0, dy1};
-      float gx[4], gy[4], vis[4], ov[4], alpha[4];
-      bool valid[4];
-      bool any_valid = false;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int i = p & 1, jy = p >> 1;
-        gx[p] = adx[i] + bdy[jy];
-        gy[p] = bdx[i] + cdy[jy];
-        const float pw = fmaf(dxv[i], gx[p], dyv[jy] * gy[p]);
-        vis[p] = __builtin_amdgcn_exp2f(pw);
-        ov[p] = q1.y * vis[p];
-        alpha[p] = fminf(ALPHA_MAX, ov[p]);
-        valid[p] = (k <= last[p]) && (pw <= 0.f) && (alpha[p] >= ALPHA_MIN);
-        any_valid |= valid[p];
-      }
-      if (__ballot(any_valid) == 0ull) continue;
       const float col[4] = {q1.z, q1.w, q2.x, q2.y};
       float g[12];
 #pragma unroll
       for (int i = 0; i < 12; ++i) g[i] = 0.f;
+      bool contributed = false;  // wave-uniform
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
+        if (!((quads >> p) & 1u)) continue;  // wave-uniform: no pixel of this quadrant can take the splat
         const int i = p & 1, jy = p >> 1;
-        const float ae = valid[p] ? alpha[p] : 0.f;
+        const float gx = adx[i] + bdy[jy];
+        const float gy = bdx[i] + cdy[jy];
+        const float pw = fmaf(dxv[i], gx, dyv[jy] * gy);
+        const float vis = __builtin_amdgcn_exp2f(pw);
+        const float ov = q1.y * vis;
+        const float alpha = fminf(ALPHA_MAX, ov);
+        const bool valid = (k <= last[p]) && (pw <= 0.f) && (alpha >= ALPHA_MIN);
+        if (__ballot(valid) == 0ull) continue;
+        contributed = true;
+        const float ae = valid ? alpha : 0.f;
         const float ra = __builtin_amdgcn_rcpf(1.f - ae);
         T[p] *= ra;
         const float fac = ae * T[p];
@@ -471,14 +480,14 @@ __global__ __launch_bounds__(64) void rasterize_bwd_kernel(
         E[p] = fmaf(-fac, cdot, E[p]);
 #pragma unroll
         for (int c = 0; c < CH; ++c) g[6 + c] = fmaf(fac, vo[p][c], g[6 + c]);
-        const float vag = (valid[p] && ov[p] <= ALPHA_MAX) ? v_alpha : 0.f;
-        g[5] = fmaf(vis[p], vag, g[5]);
-        const float z = ov[p] * vag;  // = -v_sigma
+        const float vag = (valid && ov <= ALPHA_MAX) ? v_alpha : 0.f;
+        g[5] = fmaf(vis, vag, g[5]);
+        const float z = ov * vag;  // = -v_sigma
         const float zdx = z * dxv[i], zdy = z * dyv[jy];
         g[2] = fmaf(zdx, dxv[i], g[2]);
         g[3] = fmaf(zdx, dyv[jy], g[3]);
         g[4] = fmaf(zdy, dyv[jy], g[4]);
-        const float vx = z * gx[p], vy = z * gy[p];
+        const float vx = z * gx, vy = z * gy;
         g[0] += vx;
         g[1] += vy;
         if constexpr (ABSGRAD) {
@@ -486,6 +495,7 @@ __global__ __launch_bounds__(64) void rasterize_bwd_kernel(
           g[11] += fabsf(vy);
         }
       }
+      if (!contributed) continue;
       const float r = reduce_scatter12(g, b3, b2);
       if (slot >= 0) atomicAdd(v_splats + (int64_t)__float_as_int(q2.w) * REC + slot, r * post);
     }
