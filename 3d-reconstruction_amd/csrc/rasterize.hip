@@ -364,7 +364,6 @@ __global__ __launch_bounds__(64) void rasterize_bwd_kernel(
   const float px0 = (float)ix0 + 0.5f, py0 = (float)iy0 + 0.5f;
   float T[4], E[4], vo[4][CH];
   int last[4];
-  int my_max = -1;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int x = ix0 + 8 * (p & 1), y = iy0 + 8 * (p >> 1);
@@ -397,13 +396,18 @@ __global__ __launch_bounds__(64) void rasterize_bwd_kernel(
       T[p] = Tf;
       E[p] = Tf * va;
       last[p] = last_ids[pix];
-      my_max = max(my_max, last[p]);
     }
   }
-  // wave max of last ids
-  int wmax = my_max;
+  // wave max of last ids, and per quadrant: entries behind a quadrant's last contributor skip it without evaluation
+  int qlast[4];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o));
+  for (int p = 0; p < 4; ++p) {
+    int m = last[p];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+    qlast[p] = __builtin_amdgcn_readfirstlane(m);
+  }
+  const int wmax = max(max(qlast[0], qlast[1]), max(qlast[2], qlast[3]));
   const int k_top = min(tg.end - 1, wmax);
 
   float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
@@ -458,7 +462,8 @@ __global__ __launch_bounds__(64) void rasterize_bwd_kernel(
       bool contributed = false;  // wave-uniform
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        if (!((quads >> p) & 1u)) continue;  // wave-uniform: no pixel of this quadrant can take the splat
+        // wave-uniform: no pixel of this quadrant can take the splat, or all of them stopped in front of it
+        if (!((quads >> p) & 1u) || k > qlast[p]) continue;
         const int i = p & 1, jy = p >> 1;
         const float gx = adx[i] + bdy[jy];
         const float gy = bdx[i] + cdy[jy];
