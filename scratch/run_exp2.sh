@@ -8,6 +8,6 @@ import json,sys
 n=sys.argv[1]
 d=json.loads(open(f"gpurun_out/exp_{n}.log").read().strip().splitlines()[-1])
 k=d["kernels_ms"]
-print(f"{n:10s} step {d['ms_per_step']:.3f} ms (median {d['ms_per_step_median_hip_events']:.3f})  " + "  ".join(f"{a.replace('gs_','')} {b:.4f}" for a,b in k.items() if any(s in a for s in ('proj','sh_bwd'))), flush=True)
+print(f"{n:10s} step {d['ms_per_step']:.3f} ms (median {d['ms_per_step_median_hip_events']:.3f})  " + "  ".join(f"{a.replace('gs_','')} {b:.4f}" for a,b in k.items() if any(s in a for s in ('raster',))), flush=True)
 PY
 done
