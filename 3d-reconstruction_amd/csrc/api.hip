@@ -37,7 +37,7 @@ extern "C" int gs_isect_bin_prepare(int32_t C, int32_t N, int32_t tile_w, int32_
                                     uint64_t* vis_list, int32_t* vis_counts, uint64_t* vis_masks, int32_t tile_size,
                                     int32_t* tile_counts, int32_t* isect_offsets, int64_t* total, int32_t* tile_order,
                                     int32_t* size_classes, int32_t* redo_flags, int64_t* n_isects_host,
-                                    int32_t synchronize, void* stream) {
+                                    int32_t* size_classes_host, int32_t synchronize, void* stream) {
   if (!n_isects_host || !total) return GS_ERR_INVALID_ARG;
   int st = gs_isect_bin_count(C, N, tile_w, tile_h, splats, tiles_per_gauss, n_slices, table, vis_list, vis_counts,
                               vis_masks, tile_size, stream);
@@ -52,6 +52,10 @@ extern "C" int gs_isect_bin_prepare(int32_t C, int32_t N, int32_t tile_w, int32_
   if (tile_order) {
     st = gs_raster_tile_order(n_tiles, nullptr, 0, tile_counts, tile_order, size_classes, stream);
     if (st != GS_OK) return st;
+    if (size_classes_host && size_classes) {  // lets the host skip the launches of size classes that hold no tile
+      e = hipMemcpyAsync(size_classes_host, size_classes, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+      if (e != hipSuccess) return (int)e;
+    }
   }
   if (redo_flags) {
     e = hipMemsetAsync(redo_flags, 0, ((size_t)n_tiles + 1) * sizeof(int32_t), s);
@@ -72,15 +76,16 @@ extern "C" int gs_isect_bin_build(int32_t C, int32_t N, int32_t tile_w, int32_t 
                                   const int32_t* vis_counts, const uint64_t* vis_masks, const uint32_t* table,
                                   const int32_t* isect_offsets, int64_t n_isects, const int32_t* tile_order,
                                   const int32_t* size_classes, int32_t k_target, uint64_t* pairs, int64_t* isect_ids,
-                                  int32_t* flatten_ids, int32_t* sorted_counts, void* stream) {
+                                  int32_t* flatten_ids, int32_t* sorted_counts, const int32_t* size_classes_host,
+                                  void* stream) {
   int st = gs_isect_bin_scatter_regions(C, N, tile_w, tile_h, n_slices, slices_per_group, n_regions, vis_list,
                                         vis_counts, vis_masks, table, isect_offsets, pairs, stream);
   if (st != GS_OK) return st;
   if (k_target > 0)
-    return gs_isect_tile_sort_front(C, tile_w, tile_h, isect_offsets, n_isects, tile_order, size_classes, k_target,
-                                    pairs, isect_ids, flatten_ids, sorted_counts, stream);
-  return gs_isect_tile_sort(C, tile_w, tile_h, isect_offsets, n_isects, tile_order, size_classes, pairs, isect_ids,
-                            flatten_ids, stream);
+    return gs_isect_tile_sort_front_ex(C, tile_w, tile_h, isect_offsets, n_isects, tile_order, size_classes, k_target,
+                                       pairs, isect_ids, flatten_ids, sorted_counts, size_classes_host, stream);
+  return gs_isect_tile_sort_ex(C, tile_w, tile_h, isect_offsets, n_isects, tile_order, size_classes, pairs, isect_ids,
+                               flatten_ids, size_classes_host, stream);
 }
 
 extern "C" int gs_rasterize_fwd_front(int32_t C, int32_t width, int32_t height, int32_t tile_size, int32_t channels,
@@ -90,7 +95,7 @@ extern "C" int gs_rasterize_fwd_front(int32_t C, int32_t width, int32_t height, 
                                       const int32_t* tile_order, int32_t* tile_work, int32_t* sorted_counts,
                                       int32_t* redo_flags, const float* opacity_override, int32_t n_per_camera,
                                       float* final_T, const int32_t* size_classes, uint64_t* pairs, int64_t* isect_ids,
-                                      void* stream) {
+                                      const int32_t* size_classes_host, void* stream) {
   if (!sorted_counts || !redo_flags || !tile_order || !size_classes || !pairs || !isect_ids) return GS_ERR_INVALID_ARG;
   if (tile_size < 1) return GS_ERR_INVALID_ARG;
   int st = gs_rasterize_fwd(C, width, height, tile_size, channels, splats, isect_offsets, flatten_ids, n_isects,
@@ -98,8 +103,8 @@ extern "C" int gs_rasterize_fwd_front(int32_t C, int32_t width, int32_t height, 
                             sorted_counts, redo_flags, 0, opacity_override, n_per_camera, final_T, stream);
   if (st != GS_OK) return st;
   const int32_t tw = (width + tile_size - 1) / tile_size, th = (height + tile_size - 1) / tile_size;
-  st = gs_isect_tile_sort_redo(C, tw, th, isect_offsets, n_isects, tile_order, size_classes, redo_flags, pairs,
-                               isect_ids, flatten_ids, sorted_counts, stream);
+  st = gs_isect_tile_sort_redo_ex(C, tw, th, isect_offsets, n_isects, tile_order, size_classes, redo_flags, pairs,
+                                  isect_ids, flatten_ids, sorted_counts, size_classes_host, stream);
   if (st != GS_OK) return st;
   return gs_rasterize_fwd(C, width, height, tile_size, channels, splats, isect_offsets, flatten_ids, n_isects,
                           backgrounds, ed_last_channel, render_colors, render_alphas, last_ids, tile_order, tile_work,

@@ -1064,9 +1064,19 @@ extern "C" int gs_isect_bin_scatter_regions(int32_t C, int32_t N, int32_t tile_w
   return GS_OK;
 }
 
-extern "C" int gs_isect_tile_sort(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets,
-                                  int64_t n_isects, const int32_t* tile_order, const int32_t* size_classes, uint64_t* pairs,
-                                  int64_t* isect_ids, int32_t* flatten_ids, void* stream) {
+// `sch` (host copy of size_classes, or NULL): lets the host skip the launches of size classes that hold no tile -- on the
+// shapes the reference trains at only the shortest class exists, and a launch that finds nothing to do still costs a few
+// microseconds of a launch-bound step.  Class c of the longest-first order is [sch[c-1], sch[c]) with sch[-1] = 0 and
+// sch[3] = n_tiles.
+static inline bool ts_class_empty(const int32_t* sch, int cls, int64_t n_tiles) {
+  if (!sch) return false;
+  const int64_t lo = cls > 0 ? sch[cls - 1] : 0, hi = cls < 3 ? sch[cls] : n_tiles;
+  return hi <= lo;
+}
+
+static int tile_sort_impl(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets, int64_t n_isects,
+                          const int32_t* tile_order, const int32_t* size_classes, uint64_t* pairs, int64_t* isect_ids,
+                          int32_t* flatten_ids, const int32_t* sch, void* stream) {
   if (C < 1 || tile_w < 1 || tile_h < 1 || n_isects < 0) return GS_ERR_INVALID_ARG;
   if (n_isects == 0) return GS_OK;
   if (n_isects >= ((int64_t)1 << 31)) return GS_ERR_UNSUPPORTED;
@@ -1082,16 +1092,35 @@ extern "C" int gs_isect_tile_sort(int32_t C, int32_t tile_w, int32_t tile_h, con
   if (tile_order && size_classes) {
     // longest lists first; grids are persistent and sized to the LDS-limited residency of each class; the short
     // classes run 4 / 2 waves per segment (one wave each left 8 waves per CU: 0.136 -> 0.110 ms for the chain)
-    hipLaunchKernelGGL((gs::tile_sort_kernel<6144, 0, 16>), dim3(256), dim3(1024), 0, s, GS_TS_ARGS);
-    hipLaunchKernelGGL((gs::tile_sort_kernel<2048, 1, 4>), dim3(256 * 3), dim3(256), 0, s, GS_TS_ARGS);
-    hipLaunchKernelGGL((gs::tile_sort_kernel<1024, 2, GS_TS_W2>), dim3(256 * GS_TS_G2), dim3(64 * GS_TS_W2), 0, s, GS_TS_ARGS);
-    hipLaunchKernelGGL((gs::tile_sort_kernel<512, 3, GS_TS_W3>), dim3(256 * GS_TS_G3), dim3(64 * GS_TS_W3), 0, s, GS_TS_ARGS);
+    if (!ts_class_empty(sch, 0, n_tiles))
+      hipLaunchKernelGGL((gs::tile_sort_kernel<6144, 0, 16>), dim3(256), dim3(1024), 0, s, GS_TS_ARGS);
+    if (!ts_class_empty(sch, 1, n_tiles))
+      hipLaunchKernelGGL((gs::tile_sort_kernel<2048, 1, 4>), dim3(256 * 3), dim3(256), 0, s, GS_TS_ARGS);
+    if (!ts_class_empty(sch, 2, n_tiles))
+      hipLaunchKernelGGL((gs::tile_sort_kernel<1024, 2, GS_TS_W2>), dim3(256 * GS_TS_G2), dim3(64 * GS_TS_W2), 0, s, GS_TS_ARGS);
+    if (!ts_class_empty(sch, 3, n_tiles))
+      hipLaunchKernelGGL((gs::tile_sort_kernel<512, 3, GS_TS_W3>), dim3(256 * GS_TS_G3), dim3(64 * GS_TS_W3), 0, s, GS_TS_ARGS);
   } else {
     hipLaunchKernelGGL((gs::tile_sort_kernel<2048, -1, 4>), dim3((unsigned)n_tiles), dim3(256), 0, s, GS_TS_ARGS);
   }
 #undef GS_TS_ARGS
   GS_CHECK_LAUNCH();
   return GS_OK;
+}
+
+extern "C" int gs_isect_tile_sort(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets,
+                                  int64_t n_isects, const int32_t* tile_order, const int32_t* size_classes, uint64_t* pairs,
+                                  int64_t* isect_ids, int32_t* flatten_ids, void* stream) {
+  return tile_sort_impl(C, tile_w, tile_h, isect_offsets, n_isects, tile_order, size_classes, pairs, isect_ids,
+                        flatten_ids, nullptr, stream);
+}
+
+extern "C" int gs_isect_tile_sort_ex(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets,
+                                     int64_t n_isects, const int32_t* tile_order, const int32_t* size_classes,
+                                     uint64_t* pairs, int64_t* isect_ids, int32_t* flatten_ids,
+                                     const int32_t* size_classes_host, void* stream) {
+  return tile_sort_impl(C, tile_w, tile_h, isect_offsets, n_isects, tile_order, size_classes, pairs, isect_ids,
+                        flatten_ids, size_classes_host, stream);
 }
 
 static int tile_sort_geom(int32_t C, int32_t tile_w, int32_t tile_h, int64_t n_isects, int* T, int* tile_n_bits) {
@@ -1103,10 +1132,10 @@ static int tile_sort_geom(int32_t C, int32_t tile_w, int32_t tile_h, int64_t n_i
   return GS_OK;
 }
 
-extern "C" int gs_isect_tile_sort_front(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets,
-                                        int64_t n_isects, const int32_t* tile_order, const int32_t* size_classes,
-                                        int32_t k_target, uint64_t* pairs, int64_t* isect_ids, int32_t* flatten_ids,
-                                        int32_t* sorted_counts, void* stream) {
+static int tile_sort_front_impl(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets,
+                                int64_t n_isects, const int32_t* tile_order, const int32_t* size_classes,
+                                int32_t k_target, uint64_t* pairs, int64_t* isect_ids, int32_t* flatten_ids,
+                                int32_t* sorted_counts, const int32_t* sch, void* stream) {
   int T, tile_n_bits;
   int st = tile_sort_geom(C, tile_w, tile_h, n_isects, &T, &tile_n_bits);
   if (st != GS_OK) return st;
@@ -1117,28 +1146,50 @@ extern "C" int gs_isect_tile_sort_front(int32_t C, int32_t tile_w, int32_t tile_
   const int64_t n_tiles = (int64_t)C * T;
   hipStream_t s = (hipStream_t)stream;
   uint2* pr = reinterpret_cast<uint2*>(pairs);
-  hipLaunchKernelGGL((gs::tile_sort_front_kernel<4>), dim3(256 * 6), dim3(256), 0, s, T, tile_n_bits, n_tiles,
-                     isect_offsets, n_isects, tile_order, size_classes, k_target, (const uint2*)pr, isect_ids,
-                     flatten_ids, sorted_counts);
 #define GS_TSF_ARGS T, tile_n_bits, n_tiles, isect_offsets, n_isects, tile_order, size_classes, pr, isect_ids, flatten_ids
-  // segments the front kernel deferred (sorted_counts < 0): whole-segment sort, as gs_isect_tile_sort does
-  hipLaunchKernelGGL((gs::tile_sort_kernel<6144, 0, 16>), dim3(256), dim3(1024), 0, s, GS_TSF_ARGS,
-                     (const int32_t*)sorted_counts, 0, sorted_counts);
-  hipLaunchKernelGGL((gs::tile_sort_kernel<2048, 1, 4>), dim3(256 * 3), dim3(256), 0, s, GS_TSF_ARGS,
-                     (const int32_t*)sorted_counts, 0, sorted_counts);
+  if (!(ts_class_empty(sch, 0, n_tiles) && ts_class_empty(sch, 1, n_tiles))) {  // any tile with more than TSF_MIN entries
+    hipLaunchKernelGGL((gs::tile_sort_front_kernel<4>), dim3(256 * 6), dim3(256), 0, s, T, tile_n_bits, n_tiles,
+                       isect_offsets, n_isects, tile_order, size_classes, k_target, (const uint2*)pr, isect_ids,
+                       flatten_ids, sorted_counts);
+    // segments the front kernel deferred (sorted_counts < 0): whole-segment sort, as gs_isect_tile_sort does
+    if (!ts_class_empty(sch, 0, n_tiles))
+      hipLaunchKernelGGL((gs::tile_sort_kernel<6144, 0, 16>), dim3(256), dim3(1024), 0, s, GS_TSF_ARGS,
+                         (const int32_t*)sorted_counts, 0, sorted_counts);
+    if (!ts_class_empty(sch, 1, n_tiles))
+      hipLaunchKernelGGL((gs::tile_sort_kernel<2048, 1, 4>), dim3(256 * 3), dim3(256), 0, s, GS_TSF_ARGS,
+                         (const int32_t*)sorted_counts, 0, sorted_counts);
+  }
   // short segments: sorted whole (sorted_counts was pre-filled with the list lengths by the caller)
-  hipLaunchKernelGGL((gs::tile_sort_kernel<1024, 2, GS_TS_W2>), dim3(256 * GS_TS_G2), dim3(64 * GS_TS_W2), 0, s, GS_TSF_ARGS,
-                     (const int32_t*)nullptr, 0, (int32_t*)nullptr);
-  hipLaunchKernelGGL((gs::tile_sort_kernel<512, 3, GS_TS_W3>), dim3(256 * GS_TS_G3), dim3(64 * GS_TS_W3), 0, s, GS_TSF_ARGS,
-                     (const int32_t*)nullptr, 0, (int32_t*)nullptr);
+  if (!ts_class_empty(sch, 2, n_tiles))
+    hipLaunchKernelGGL((gs::tile_sort_kernel<1024, 2, GS_TS_W2>), dim3(256 * GS_TS_G2), dim3(64 * GS_TS_W2), 0, s,
+                       GS_TSF_ARGS, (const int32_t*)nullptr, 0, (int32_t*)nullptr);
+  if (!ts_class_empty(sch, 3, n_tiles))
+    hipLaunchKernelGGL((gs::tile_sort_kernel<512, 3, GS_TS_W3>), dim3(256 * GS_TS_G3), dim3(64 * GS_TS_W3), 0, s,
+                       GS_TSF_ARGS, (const int32_t*)nullptr, 0, (int32_t*)nullptr);
   GS_CHECK_LAUNCH();
   return GS_OK;
 }
 
-extern "C" int gs_isect_tile_sort_redo(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets,
-                                       int64_t n_isects, const int32_t* tile_order, const int32_t* size_classes,
-                                       const int32_t* redo_flags, uint64_t* pairs, int64_t* isect_ids,
-                                       int32_t* flatten_ids, int32_t* sorted_counts, void* stream) {
+extern "C" int gs_isect_tile_sort_front(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets,
+                                        int64_t n_isects, const int32_t* tile_order, const int32_t* size_classes,
+                                        int32_t k_target, uint64_t* pairs, int64_t* isect_ids, int32_t* flatten_ids,
+                                        int32_t* sorted_counts, void* stream) {
+  return tile_sort_front_impl(C, tile_w, tile_h, isect_offsets, n_isects, tile_order, size_classes, k_target, pairs,
+                              isect_ids, flatten_ids, sorted_counts, nullptr, stream);
+}
+
+extern "C" int gs_isect_tile_sort_front_ex(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets,
+                                           int64_t n_isects, const int32_t* tile_order, const int32_t* size_classes,
+                                           int32_t k_target, uint64_t* pairs, int64_t* isect_ids, int32_t* flatten_ids,
+                                           int32_t* sorted_counts, const int32_t* size_classes_host, void* stream) {
+  return tile_sort_front_impl(C, tile_w, tile_h, isect_offsets, n_isects, tile_order, size_classes, k_target, pairs,
+                              isect_ids, flatten_ids, sorted_counts, size_classes_host, stream);
+}
+
+static int tile_sort_redo_impl(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets,
+                               int64_t n_isects, const int32_t* tile_order, const int32_t* size_classes,
+                               const int32_t* redo_flags, uint64_t* pairs, int64_t* isect_ids, int32_t* flatten_ids,
+                               int32_t* sorted_counts, const int32_t* sch, void* stream) {
   int T, tile_n_bits;
   int st = tile_sort_geom(C, tile_w, tile_h, n_isects, &T, &tile_n_bits);
   if (st != GS_OK) return st;
@@ -1149,11 +1200,30 @@ extern "C" int gs_isect_tile_sort_redo(int32_t C, int32_t tile_w, int32_t tile_h
   const int64_t n_tiles = (int64_t)C * T;
   hipStream_t s = (hipStream_t)stream;
   uint2* pr = reinterpret_cast<uint2*>(pairs);
-  hipLaunchKernelGGL((gs::tile_sort_kernel<6144, 0, 16>), dim3(256), dim3(1024), 0, s, GS_TSF_ARGS, redo_flags, 1,
-                     sorted_counts);
-  hipLaunchKernelGGL((gs::tile_sort_kernel<2048, 1, 4>), dim3(256 * 3), dim3(256), 0, s, GS_TSF_ARGS, redo_flags, 1,
-                     sorted_counts);
+  if (!ts_class_empty(sch, 0, n_tiles))
+    hipLaunchKernelGGL((gs::tile_sort_kernel<6144, 0, 16>), dim3(256), dim3(1024), 0, s, GS_TSF_ARGS, redo_flags, 1,
+                       sorted_counts);
+  if (!ts_class_empty(sch, 1, n_tiles))
+    hipLaunchKernelGGL((gs::tile_sort_kernel<2048, 1, 4>), dim3(256 * 3), dim3(256), 0, s, GS_TSF_ARGS, redo_flags, 1,
+                       sorted_counts);
 #undef GS_TSF_ARGS
   GS_CHECK_LAUNCH();
   return GS_OK;
+}
+
+extern "C" int gs_isect_tile_sort_redo(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets,
+                                       int64_t n_isects, const int32_t* tile_order, const int32_t* size_classes,
+                                       const int32_t* redo_flags, uint64_t* pairs, int64_t* isect_ids,
+                                       int32_t* flatten_ids, int32_t* sorted_counts, void* stream) {
+  return tile_sort_redo_impl(C, tile_w, tile_h, isect_offsets, n_isects, tile_order, size_classes, redo_flags, pairs,
+                             isect_ids, flatten_ids, sorted_counts, nullptr, stream);
+}
+
+extern "C" int gs_isect_tile_sort_redo_ex(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets,
+                                          int64_t n_isects, const int32_t* tile_order, const int32_t* size_classes,
+                                          const int32_t* redo_flags, uint64_t* pairs, int64_t* isect_ids,
+                                          int32_t* flatten_ids, int32_t* sorted_counts,
+                                          const int32_t* size_classes_host, void* stream) {
+  return tile_sort_redo_impl(C, tile_w, tile_h, isect_offsets, n_isects, tile_order, size_classes, redo_flags, pairs,
+                             isect_ids, flatten_ids, sorted_counts, size_classes_host, stream);
 }

@@ -65,12 +65,17 @@ _SIGNATURES = {
     "gs_isect_bin_count": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, c_int32, _P, _P, _P, _P, c_int32,
                                           _P]),
     "gs_isect_bin_prepare": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, c_int32, _P, _P, _P, _P, c_int32,
-                                            _P, _P, _P, _P, _P, _P, _P, c_int32, _P]),
+                                            _P, _P, _P, _P, _P, _P, _P, _P, c_int32, _P]),
     "gs_stream_synchronize": (ctypes.c_int, [_P]),
     "gs_visibility_prefix": (ctypes.c_int, [c_int32, c_int32, _P, _P, _P, _P, c_int64, _P]),
-    "gs_isect_bin_build": (ctypes.c_int, [c_int32] * 7 + [_P] * 5 + [c_int64, _P, _P, c_int32, _P, _P, _P, _P, _P]),
+    "gs_isect_bin_build": (ctypes.c_int, [c_int32] * 7 + [_P] * 5 + [c_int64, _P, _P, c_int32, _P, _P, _P, _P, _P, _P]),
+    "gs_isect_tile_sort_ex": (ctypes.c_int, [c_int32, c_int32, c_int32, _P, c_int64, _P, _P, _P, _P, _P, _P, _P]),
+    "gs_isect_tile_sort_front_ex": (ctypes.c_int, [c_int32, c_int32, c_int32, _P, c_int64, _P, _P, c_int32, _P, _P, _P,
+                                                   _P, _P, _P]),
+    "gs_isect_tile_sort_redo_ex": (ctypes.c_int, [c_int32, c_int32, c_int32, _P, c_int64, _P, _P, _P, _P, _P, _P, _P,
+                                                  _P, _P]),
     "gs_rasterize_fwd_front": (ctypes.c_int, [c_int32] * 5 + [_P, _P, _P, c_int64, _P, c_int32] + [_P] * 8 +
-                               [c_int32, _P, _P, _P, _P, _P]),
+                               [c_int32, _P, _P, _P, _P, _P, _P]),
     "gs_isect_bin_offsets": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P]),
     "gs_isect_bin_scatter": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, c_int32, _P, _P, _P, _P]),
     "gs_isect_bin_scatter_regions": (ctypes.c_int, [c_int32] * 7 + [_P] * 7),

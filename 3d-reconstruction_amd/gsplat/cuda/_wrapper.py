@@ -410,6 +410,7 @@ class FrontSort:
         if redo_flags is None:  # (the composite prepare call zeroes the one it is given)
             redo_flags = torch.zeros(sorted_counts.numel() + 1, device=sorted_counts.device, dtype=torch.int32)
         self.redo_flags = redo_flags
+        self.size_classes_host = None  # ctypes int32[3], when the host has read the size classes
         self.complete = False
 
     def redo(self) -> None:
@@ -451,7 +452,7 @@ def _host_scalar() -> Tensor:
     key = threading.get_ident()
     t = _host_scalars.get(key)
     if t is None:
-        t = _host_scalars[key] = torch.zeros(1, dtype=torch.int64).pin_memory()
+        t = _host_scalars[key] = torch.zeros(3, dtype=torch.int64).pin_memory()  # n_isects | 3 x int32 size classes
     return t
 
 
@@ -515,7 +516,7 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
     want_order = C * T <= 131072
     use_front = front and want_order
     fused = FUSED_LAUNCHES and REGION_SCATTER and not any(B.profiling_active(k) for k in _ISECT_LABELS)
-    order = n_long = redo_flags = None
+    order = n_long = redo_flags = sc_host = None
     if want_order:
         order = torch.empty(C * T, device=dev, dtype=torch.int32)
         n_long = torch.empty(3, device=dev, dtype=torch.int32)  # size classes of the order
@@ -529,13 +530,20 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
             B.check(lib.gs_isect_bin_prepare(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
                                              n_slices, B.ptr(table), B.ptr(vis_list), B.ptr(vis_cnt), B.ptr(vis_masks),
                                              int(cull_tile_size), B.ptr(counts), B.ptr(offsets), B.ptr(total),
-                                             B.ptr(order), B.ptr(n_long), B.ptr(redo_flags), host_n.data_ptr(), 0, st),
+                                             B.ptr(order), B.ptr(n_long), B.ptr(redo_flags), host_n.data_ptr(),
+                                             host_n.data_ptr() + 8 if want_order else None, 0, st),
                     "gs_isect_bin_prepare")
             if while_counting is not None:
                 while_counting()
                 while_counting = None
             B.check(lib.gs_stream_synchronize(st), "gs_stream_synchronize")
         n_isects = int(host_n[0])
+        if want_order:
+            # host copy of the tile order's size classes: launches for classes that hold no tile are skipped, and
+            # without a tile above 1024 entries there is no front to sort first
+            sc_host = (ctypes.c_int32 * 3)(*host_n.view(torch.int32)[2:5].tolist())
+            if sc_host[1] == 0:
+                use_front = False
     else:
         with B.device_guard(dev), B.timed("gs_isect_bin_count", dev):
             B.check(lib.gs_isect_bin_count(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
@@ -561,11 +569,13 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
             B.check(lib.gs_isect_bin_build(C, N, tile_width, tile_height, n_slices, group, regions, B.ptr(vis_list),
                                            B.ptr(vis_cnt), B.ptr(vis_masks), B.ptr(table), B.ptr(offsets), n_isects,
                                            B.ptr(order), B.ptr(n_long), FRONT_K_TARGET if use_front else 0,
-                                           B.ptr(pairs), B.ptr(isect_ids), B.ptr(flatten_ids), B.ptr(counts), st),
+                                           B.ptr(pairs), B.ptr(isect_ids), B.ptr(flatten_ids), B.ptr(counts),
+                                           ctypes.addressof(sc_host) if sc_host is not None else None, st),
                     "gs_isect_bin_build")
         if use_front:
             fs = FrontSort((C, tile_width, tile_height), offsets, order, n_long, pairs, isect_ids, flatten_ids, counts,
                            redo_flags)
+            fs.size_classes_host = sc_host
             return isect_ids, flatten_ids, offsets, order, fs
         return isect_ids, flatten_ids, offsets, order, None
     with B.device_guard(dev), B.timed("gs_isect_bin_scatter", dev):
@@ -629,7 +639,10 @@ def launch_raster_fwd(splats, offsets, flatten_ids, order, fs, bg, geom, rc, ra,
                                                    B.ptr(ra), B.ptr(last_ids), B.ptr(order), B.ptr(work),
                                                    B.ptr(fs.sorted_counts), B.ptr(fs.redo_flags), B.ptr(opac_override),
                                                    N, B.ptr(final_T), B.ptr(fs.n_long), B.ptr(fs.pairs),
-                                                   B.ptr(fs.isect_ids), B.stream_handle(dev)),
+                                                   B.ptr(fs.isect_ids),
+                                                   ctypes.addressof(fs.size_classes_host)
+                                                   if fs.size_classes_host is not None else None,
+                                                   B.stream_handle(dev)),
                     "gs_rasterize_fwd_front")
         return
     raster(0)

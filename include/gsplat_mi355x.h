@@ -365,20 +365,38 @@ int gs_isect_bin_prepare(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, c
                          const int32_t* tiles_per_gauss, int32_t n_slices, uint32_t* table, uint64_t* vis_list,
                          int32_t* vis_counts, uint64_t* vis_masks, int32_t tile_size, int32_t* tile_counts,
                          int32_t* isect_offsets, int64_t* total, int32_t* tile_order, int32_t* size_classes,
-                         int32_t* redo_flags, int64_t* n_isects_host, int32_t synchronize, void* stream);
+                         int32_t* redo_flags, int64_t* n_isects_host,
+                         int32_t* size_classes_host /* out int32[3] or NULL: host copy of size_classes */,
+                         int32_t synchronize, void* stream);
 int gs_stream_synchronize(void* stream); /* hipStreamSynchronize */
 int gs_isect_bin_build(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, int32_t n_slices,
                        int32_t slices_per_group, int32_t n_regions, const uint64_t* vis_list, const int32_t* vis_counts,
                        const uint64_t* vis_masks, const uint32_t* table, const int32_t* isect_offsets, int64_t n_isects,
                        const int32_t* tile_order, const int32_t* size_classes, int32_t k_target, uint64_t* pairs,
-                       int64_t* isect_ids, int32_t* flatten_ids, int32_t* sorted_counts, void* stream);
+                       int64_t* isect_ids, int32_t* flatten_ids, int32_t* sorted_counts,
+                       const int32_t* size_classes_host /* or NULL */, void* stream);
 int gs_rasterize_fwd_front(int32_t C, int32_t width, int32_t height, int32_t tile_size, int32_t channels,
                            const float* splats, const int32_t* isect_offsets, int32_t* flatten_ids, int64_t n_isects,
                            const float* backgrounds, int32_t ed_last_channel, float* render_colors,
                            float* render_alphas, int32_t* last_ids, const int32_t* tile_order, int32_t* tile_work,
                            int32_t* sorted_counts, int32_t* redo_flags, const float* opacity_override,
                            int32_t n_per_camera, float* final_T, const int32_t* size_classes, uint64_t* pairs,
-                           int64_t* isect_ids, void* stream);
+                           int64_t* isect_ids, const int32_t* size_classes_host /* or NULL */, void* stream);
+/* The three sort entry points with a HOST copy of size_classes (from gs_isect_bin_prepare; NULL = as the plain entry
+ * points): launches for size classes that hold no tile are skipped -- on launch-bound shapes only the shortest class
+ * exists, and a launch that finds nothing to do still costs microseconds.  gs_isect_tile_sort_front_ex with no tile
+ * above 1024 entries launches neither the front kernel nor the long classes. */
+int gs_isect_tile_sort_ex(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets, int64_t n_isects,
+                          const int32_t* tile_order, const int32_t* size_classes, uint64_t* pairs, int64_t* isect_ids,
+                          int32_t* flatten_ids, const int32_t* size_classes_host, void* stream);
+int gs_isect_tile_sort_front_ex(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets, int64_t n_isects,
+                                const int32_t* tile_order, const int32_t* size_classes, int32_t k_target,
+                                uint64_t* pairs, int64_t* isect_ids, int32_t* flatten_ids, int32_t* sorted_counts,
+                                const int32_t* size_classes_host, void* stream);
+int gs_isect_tile_sort_redo_ex(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets, int64_t n_isects,
+                               const int32_t* tile_order, const int32_t* size_classes, const int32_t* redo_flags,
+                               uint64_t* pairs, int64_t* isect_ids, int32_t* flatten_ids, int32_t* sorted_counts,
+                               const int32_t* size_classes_host, void* stream);
 
 /* ---- packed mode ------------------------------------------------------------------------------ */
 /* Emits, in ascending (camera, gaussian) order, the rows with radii > 0. cum_excl = exclusive scan of

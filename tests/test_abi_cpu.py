@@ -197,11 +197,11 @@ def test_entry_points_reject_bad_arguments_before_any_launch():
     assert L.gs_isect_bin_count(1, 10, 4, 4, P, P, 1, P, None, None, P, 16, None) == INVALID  # tile masks without the lists
     assert L.gs_isect_bin_scatter_regions(1, 10, 4, 4, 1, 0, 2, P, P, None, P, P, P, None) == INVALID  # slices_per_group < 1
     # composite launches: rejected before their first launch
-    assert L.gs_isect_bin_prepare(1, 10, 4, 4, P, P, 1, P, P, P, None, 0, P, P, P, P, P, None, None, 1, None) == INVALID  # no host scalar
-    assert L.gs_isect_bin_prepare(1, 10, too_many, 1, P, P, 1, P, P, P, None, 0, P, P, P, P, P, None, P, 1, None) == UNSUPPORTED
-    assert L.gs_isect_bin_build(1, 10, 4, 4, 1, 0, 2, P, P, None, P, P, 5, P, P, 0, P, P, P, P, None) == INVALID  # slices_per_group < 1
+    assert L.gs_isect_bin_prepare(1, 10, 4, 4, P, P, 1, P, P, P, None, 0, P, P, P, P, P, None, None, None, 1, None) == INVALID  # no host scalar
+    assert L.gs_isect_bin_prepare(1, 10, too_many, 1, P, P, 1, P, P, P, None, 0, P, P, P, P, P, None, P, None, 1, None) == UNSUPPORTED
+    assert L.gs_isect_bin_build(1, 10, 4, 4, 1, 0, 2, P, P, None, P, P, 5, P, P, 0, P, P, P, P, None, None) == INVALID  # slices_per_group < 1
     assert L.gs_rasterize_fwd_front(1, 64, 64, 16, 4, P, P, P, 5, None, 0, P, P, P, P, None, None, P, None, 10, None, P, P, P,
-                                    None) == INVALID  # no sorted_counts
+                                    None, None) == INVALID  # no sorted_counts
     assert L.gs_densify_accumulate(0, 10, P, P, 16, 1.0, 1.0, 1.0, 0, P, P, P, None) == INVALID   # C < 1
     assert L.gs_exclusive_scan_workspace_bytes(1000) > 0
     for code, word in ((INVALID, b"invalid"), (UNSUPPORTED, b"unsupported"), (WORKSPACE, b"workspace")):
