@@ -88,8 +88,11 @@ __device__ __forceinline__ unsigned long long bin_walk(uint32_t* cnt, bool valid
       const float xmax = __builtin_amdgcn_sqrtf(fmaxf(0.f, g.C * L * rdet));
       const float dyr = -g.Bh * xmax * __builtin_amdgcn_rcpf(g.C);
       const float rtile = __builtin_amdgcn_rcpf(tile_px);
+      // an opacity that cannot reach 1/255 even at the mean (zeroed instances, rigid.py:493): no tile takes the pair,
+      // whatever the conic looks like (rect_may_touch says the same: opacity * exp2(<= 0) stays under the threshold)
+      const bool never = g.op < ALPHA_MIN * 0.999f;
       int trow0 = y0 * tile_w, sh = 0;
-      for (int ti = y0; ti < y1; ++ti, trow0 += tile_w, sh += w) {
+      for (int ti = y0; ti < (never ? y0 : y1); ++ti, trow0 += tile_w, sh += w) {
         int lo = x0, hi = x1 - 1;
         if (sane) {
           const float dyh = g.my - ((float)ti * tile_px + 0.5f), dyl = dyh - ext;

@@ -23,6 +23,7 @@ def _project(dev, N, C, W, H, seed=3, extent=15.0):
 
     g = synth_scene.make_gaussians(N, sh_degree=None, extent=extent, seed=seed)
     vm, Ks = synth_scene.make_cameras(C, W, H)
+    g["opacities"][::7] = 0.0  # instances that are invalid in this frame arrive with opacity exactly 0
     g = {k: v.to(dev) for k, v in g.items()}
     params = Wm._make_params(N, C, W, H, 16, 0.3, 0.1, 1e10, 0.0, True, B.GS_COLOR_N, 3, None, 0, True)
     with torch.no_grad():
@@ -79,6 +80,12 @@ def test_culled_lists_are_subsequences_and_drop_only_invisible_pairs(gpu_device,
         worst = float(alpha.reshape(alpha.shape[0], -1).max(dim=1).values.max())
         print(f"[cull] dropped {dropped.shape[0]} pairs, their largest alpha on the tile {worst:.6f} (1/255 = {1 / 255:.6f})")
         assert worst < 1.0 / 255.0
+    # zero-opacity splats leave no pair behind unless their box is too large to be culled (> 64 tiles)
+    rec_c = splats.reshape(-1, 16)[fids_c.long()].cpu()
+    zero_left = rec_c[:, 5] == 0
+    if bool(zero_left.any()):
+        boxes = tpg.reshape(-1)[fids_c.long()].cpu()[zero_left]
+        assert int(boxes.min()) > 64, "a zero-opacity splat with a small box kept a pair"
 
 
 @pytest.mark.parametrize("packed", [False, True])
