@@ -79,7 +79,7 @@ extern "C" int gs_isect_bin_build(int32_t C, int32_t N, int32_t tile_w, int32_t 
                                   int32_t* flatten_ids, int32_t* sorted_counts, const int32_t* size_classes_host,
                                   void* stream) {
   int st = gs_isect_bin_scatter_regions(C, N, tile_w, tile_h, n_slices, slices_per_group, n_regions, vis_list,
-                                        vis_counts, vis_masks, table, isect_offsets, pairs, stream);
+                                        vis_counts, vis_masks, table, isect_offsets, sorted_counts, pairs, stream);
   if (st != GS_OK) return st;
   if (k_target > 0)
     return gs_isect_tile_sort_front_ex(C, tile_w, tile_h, isect_offsets, n_isects, tile_order, size_classes, k_target,

@@ -41,6 +41,21 @@ constexpr int BIN_MAX_TILES = 16384;    // per camera: LDS histogram of 64 KiB
 // scatter writes, the sort orders and both rasterizer passes stage.  The decision is taken ONCE, here: a box of up to
 // 64 tiles leaves a bit mask (bit t = tile t of the box in row-major order) beside its visible-list entry and the
 // scatter follows the mask, so the two passes agree by construction; larger boxes (rare) are not culled.
+// t / w and t % w for 0 <= t < 2^14, 1 <= w <= 2^14 through a float reciprocal (`rw` ~ 1 / w to an ulp): (t + 1/2) / w is
+// at least 1 / (2 w) away from every integer, far more than the product's rounding error, so the truncation is exact.
+// (The integer division the compiler emits instead is ~25 instructions per quotient.)
+__device__ __forceinline__ void div_small(int t, int w, float rw, int& q, int& r) {
+  q = (int)(((float)t + 0.5f) * rw);
+  r = t - q * w;
+}
+
+// value of lane `src` (wave-uniform): a v_readlane into a scalar register where __shfl would go through the LDS crossbar
+__device__ __forceinline__ int lane_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ uint32_t lane_u(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+__device__ __forceinline__ float lane_f(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
 struct CullRec {
   float mx, my, A, Bh, C, op;
 };
@@ -116,13 +131,16 @@ __device__ __forceinline__ unsigned long long bin_walk(uint32_t* cnt, bool valid
     while (big) {
       const int src = __ffsll((long long)big) - 1;
       big &= big - 1;
-      const int b_cnt = __shfl(cntg, src), b_x0 = __shfl(x0, src), b_y0 = __shfl(y0, src);
-      const int b_w = __shfl(x1, src) - b_x0;
-      const uint32_t b_d = __shfl(dbits, src), b_idx = __shfl(idx, src);
+      const int b_cnt = lane_i(cntg, src), b_x0 = lane_i(x0, src), b_y0 = lane_i(y0, src);
+      const int b_w = lane_i(x1, src) - b_x0;
+      const float b_rw = __builtin_amdgcn_rcpf((float)b_w);
+      const uint32_t b_d = lane_u(dbits, src), b_idx = lane_u(idx, src);
       if (CULL && b_cnt <= 64) {
-        const float mx = __shfl(g.mx, src), my = __shfl(g.my, src), A = __shfl(g.A, src), Bh = __shfl(g.Bh, src);
-        const float Cc = __shfl(g.C, src), op = __shfl(g.op, src);
-        const int ti = b_y0 + lane / b_w, tj = b_x0 + lane % b_w;
+        const float mx = lane_f(g.mx, src), my = lane_f(g.my, src), A = lane_f(g.A, src), Bh = lane_f(g.Bh, src);
+        const float Cc = lane_f(g.C, src), op = lane_f(g.op, src);
+        int dq, dr;
+        div_small(lane, b_w, b_rw, dq, dr);
+        const int ti = b_y0 + dq, tj = b_x0 + dr;
         const bool hit = lane < b_cnt && rect_may_touch(mx, my, A, Bh, Cc, op, (float)tj * tile_px + 0.5f,
                                                         (float)ti * tile_px + 0.5f, tile_px - 1.f);
         const unsigned long long bal = __ballot(hit);
@@ -131,8 +149,9 @@ __device__ __forceinline__ unsigned long long bin_walk(uint32_t* cnt, bool valid
         continue;
       }
       for (int t = lane; t < b_cnt; t += 64) {
-        const int ti = b_y0 + t / b_w, tj = b_x0 + t % b_w;
-        const uint32_t pos = atomicAdd(&cnt[ti * tile_w + tj], 1u);
+        int dq, dr;
+        div_small(t, b_w, b_rw, dq, dr);
+        const uint32_t pos = atomicAdd(&cnt[(b_y0 + dq) * tile_w + b_x0 + dr], 1u);
         if (SCATTER) pairs[pos] = make_uint2(b_d, b_idx);
       }
     }
@@ -252,6 +271,114 @@ __global__ __launch_bounds__(BIN_THREADS) void isect_bin_kernel(int32_t N, int32
 // G * R times as long from a cursor table R times smaller.  Which slot a hit gets inside its tile segment differs from
 // the slice scatter's; the per-tile sort that follows fixes the order completely either way.
 // CULL: the count pass's tile masks (see bin_drain) say which tiles of a box of <= 64 tiles take the pair.
+// The walk of the visible lists of slices [sa, sb) (sa < sb) of one camera, clipped to the band [ty0, ty1):
+// `emit(band tile, depth bits, row)` per pair.  A wave takes every 16th batch of 64 entries of each slice in turn and
+// requests its NEXT batch (entry + mask, across slice ends) before it walks the current one, so the two loads at the
+// head of a batch are not waited for in sequence (worth 1-2 us of 48 at 1242x375 x 5).
+template <bool CULL, class Emit>
+__device__ __forceinline__ void region_walk(int sa, int sb, const int32_t* __restrict__ cnt_row,
+                                            const uint4* __restrict__ list_row, const uint2* __restrict__ mask_row,
+                                            int seg_cap, int ty0, int ty1, int tile_w, Emit emit) {
+  const int tid = threadIdx.x, lane = tid & 63, wave0 = (tid >> 6) * 64;
+  int s = sa, e0 = wave0;  // the batch about to be fetched (wave-uniform)
+  int n = cnt_row[s], n_next = s + 1 < sb ? cnt_row[s + 1] : 0;
+  auto settle = [&]() {  // skip to the next slice that still has a batch for this wave
+    while (s < sb && e0 >= n) {
+      ++s;
+      e0 = wave0;
+      n = n_next;
+      n_next = s + 1 < sb ? cnt_row[s + 1] : 0;
+    }
+  };
+  uint4 en_n = make_uint4(0u, 0u, 0u, 0u);
+  uint2 mm_n = make_uint2(0u, 0u);
+  bool v_n = false;
+  auto fetch = [&]() {
+    v_n = s < sb && e0 + lane < n;
+    if (v_n) {
+      const int64_t at = (int64_t)s * seg_cap + e0 + lane;
+      en_n = list_row[at];
+      if (CULL) mm_n = mask_row[at];
+    }
+  };
+  settle();
+  bool have = s < sb;
+  fetch();
+  while (have) {
+    const uint4 en = en_n;
+    const uint2 mm = mm_n;
+    const bool valid = v_n;
+    e0 += BIN_THREADS;
+    settle();
+    have = s < sb;
+    fetch();
+    int cntg = 0, x0 = 0, y0 = 0, x1 = 0;
+    uint32_t idx = 0, dbits = 0;
+    unsigned long long m = 0ull;  // CULL: the band's part of the tile mask, bit 0 = tile (x0, y0)
+    bool masked = false;
+    if (valid) {
+      idx = en.x; dbits = en.w;
+      x0 = en.y & 0xffff; x1 = en.z & 0xffff;
+      const int y0o = (int)(en.y >> 16), y1o = (int)(en.z >> 16), w = x1 - x0;
+      y0 = max(y0o, ty0);
+      const int rows = max(0, min(y1o, ty1) - y0);
+      cntg = rows * w;
+      if (CULL && (y1o - y0o) * w <= 64) {
+        masked = true;
+        if (cntg > 0) {
+          m = (((unsigned long long)mm.y << 32) | mm.x) >> ((y0 - y0o) * w);
+          if (cntg < 64) m &= (1ull << cntg) - 1ull;
+        }
+        cntg = __popcll(m);  // pairs this lane will write
+      }
+    }
+    if (cntg > 0 && cntg <= BIN_COOP) {
+      if (CULL && masked) {
+        // one flat loop over the set bits (a loop over the rows with one over the row's bits inside runs, wave-wide,
+        // the sum over rows of the longest row): bit j -> (row, column) of the box by a float reciprocal, exact for
+        // j < 64, w <= 64 ((j + 1/2) / w stays 1/128 away from every integer)
+        const int w = x1 - x0;
+        const float rw = __builtin_amdgcn_rcpf((float)w);
+        const int base = (y0 - ty0) * tile_w + x0;
+        while (m) {
+          const int j = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          int q, rem;
+          div_small(j, w, rw, q, rem);
+          emit(base + q * tile_w + rem, dbits, idx);
+        }
+      } else {
+        int tj = x0, trow0 = (y0 - ty0) * tile_w;
+        for (int t = 0; t < cntg; ++t) {
+          emit(trow0 + tj, dbits, idx);
+          if (++tj == x1) { tj = x0; trow0 += tile_w; }
+        }
+      }
+    }
+    unsigned long long big = __ballot(cntg > BIN_COOP);
+    while (big) {
+      const int src = __ffsll((long long)big) - 1;
+      big &= big - 1;
+      const int b_cnt = lane_i(cntg, src), b_x0 = lane_i(x0, src), b_y0 = lane_i(y0, src) - ty0;
+      const int b_w = lane_i(x1, src) - b_x0;
+      const float b_rw = __builtin_amdgcn_rcpf((float)b_w);
+      const uint32_t b_d = lane_u(dbits, src), b_idx = lane_u(idx, src);
+      int dq, dr;
+      if (CULL && lane_i((int)masked, src)) {
+        const uint32_t mlo = lane_u((uint32_t)m, src), mhi = lane_u((uint32_t)(m >> 32), src);
+        const unsigned long long bm = ((unsigned long long)mhi << 32) | mlo;
+        div_small(lane, b_w, b_rw, dq, dr);
+        if ((bm >> lane) & 1ull) emit((b_y0 + dq) * tile_w + b_x0 + dr, b_d, b_idx);
+        continue;
+      }
+      for (int t = lane; t < b_cnt; t += 64) {
+        div_small(t, b_w, b_rw, dq, dr);
+        emit((b_y0 + dq) * tile_w + b_x0 + dr, b_d, b_idx);
+      }
+    }
+  }
+}
+
 template <bool CULL>
 __global__ __launch_bounds__(BIN_THREADS) void isect_region_scatter_kernel(
     int32_t tile_w, int32_t tile_h, int32_t T, int32_t n_slices, int32_t G, int32_t R, int32_t seg_cap,
@@ -259,7 +386,7 @@ __global__ __launch_bounds__(BIN_THREADS) void isect_region_scatter_kernel(
     const uint32_t* __restrict__ table, const int32_t* __restrict__ offsets, uint2* __restrict__ pairs) {
   extern __shared__ uint32_t cur[];  // [band tiles]
   const int c = blockIdx.y, g = blockIdx.x / R, r = blockIdx.x - g * R;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x;
   const int ty0 = (int)((int64_t)r * tile_h / R), ty1 = (int)((int64_t)(r + 1) * tile_h / R);
   const int t0 = ty0 * tile_w, nt = (ty1 - ty0) * tile_w;
   if (nt == 0) return;
@@ -269,82 +396,115 @@ __global__ __launch_bounds__(BIN_THREADS) void isect_region_scatter_kernel(
   const int32_t* orow = offsets + (int64_t)c * T + t0;
   for (int t = tid; t < nt; t += BIN_THREADS) cur[t] = (uint32_t)orow[t] + trow[t];
   __syncthreads();
-  for (int s = s0; s < s1; ++s) {
-    const int n = vis_cnt[c * n_slices + s];
-    const uint4* seg = vis_list + ((int64_t)c * n_slices + s) * seg_cap;
-    const uint2* mseg = CULL ? vis_mask + ((int64_t)c * n_slices + s) * seg_cap : nullptr;
-    for (int e0 = (tid >> 6) * 64; e0 < n; e0 += BIN_THREADS) {
-      const int e = e0 + lane;
-      int cntg = 0, x0 = 0, y0 = 0, x1 = 0, rows = 0;
-      uint32_t idx = 0, dbits = 0;
-      unsigned long long m = 0ull;  // CULL: the band's part of the tile mask, bit 0 = tile (x0, y0)
-      bool masked = false;
-      if (e < n) {
-        const uint4 en = seg[e];
-        idx = en.x; dbits = en.w;
-        x0 = en.y & 0xffff; x1 = en.z & 0xffff;
-        const int y0o = (int)(en.y >> 16), y1o = (int)(en.z >> 16), w = x1 - x0;
-        y0 = max(y0o, ty0);
-        rows = max(0, min(y1o, ty1) - y0);
-        cntg = rows * w;
-        if (CULL && (y1o - y0o) * w <= 64) {
-          masked = true;
-          if (cntg > 0) {
-            const uint2 mm = mseg[e];
-            m = (((unsigned long long)mm.y << 32) | mm.x) >> ((y0 - y0o) * w);
-            if (cntg < 64) m &= (1ull << cntg) - 1ull;
-          }
-          cntg = __popcll(m);  // pairs this lane will write
-        }
+  region_walk<CULL>(s0, s1, vis_cnt + (int64_t)c * n_slices, vis_list + (int64_t)c * n_slices * seg_cap,
+                    CULL ? vis_mask + (int64_t)c * n_slices * seg_cap : nullptr, seg_cap, ty0, ty1, tile_w,
+                    [&](int t, uint32_t dbits, uint32_t idx) {
+                      const uint32_t pos = atomicAdd(&cur[t], 1u);
+                      pairs[pos] = make_uint2(dbits, idx);
+                    });
+}
+
+// The same scatter STAGED through LDS.  The direct form above issues one 8-B store per pair from lanes that sit in
+// different tiles: ~10 distinct lines per store instruction, each line dribbled out over the whole walk and most of them
+// leaving L2 partially written (3.2x write amplification, profiles/traffic.json r02_v3).  Here the workgroup knows how
+// many pairs its slices put into every tile of its band (a difference of two rows of the slice-prefix table), so it
+// counting-sorts them by tile in LDS first and then writes each tile's run in one piece, consecutive lanes on
+// consecutive entries.  The slices of the group are taken in chunks whose pairs fit the staging area (halving the chunk
+// until they do; a single slice that still does not fit is scattered directly).
+// What it buys (profiles/r02_ab_runs.txt item 12): long runs make ONE band per camera affordable at 1242x375, which
+// halves the list reads and the lanes that idle on out-of-band entries (48.1 -> 42.8 us); at 9 600 tiles the direct
+// form's partial lines no longer thrash L2 (113 -> 94 us).  With the same bands as the direct form it is no faster:
+// with emission switched off altogether the walk alone takes 34 of the 48 us (10.7 wave-iterations per 64 entries at
+// 23 % lane use: the longest mask of the batch sets the trip count) -- the stores were never the larger part.
+template <bool CULL>
+__global__ __launch_bounds__(BIN_THREADS) void isect_region_scatter_staged_kernel(
+    int32_t tile_w, int32_t tile_h, int32_t T, int32_t n_slices, int32_t G, int32_t R, int32_t seg_cap,
+    int32_t nt_max, int32_t cap, const uint4* __restrict__ vis_list, const int32_t* __restrict__ vis_cnt,
+    const uint2* __restrict__ vis_mask, const uint32_t* __restrict__ table, const int32_t* __restrict__ offsets,
+    const int32_t* __restrict__ tile_counts, uint2* __restrict__ pairs) {
+  extern __shared__ uint32_t lds_raw[];
+  uint32_t* lcur = lds_raw;                                        // [nt_max] staging cursor per band tile
+  uint32_t* gdelta = lds_raw + nt_max;                             // [nt_max] global position - staging position
+  uint2* stage = reinterpret_cast<uint2*>(lds_raw + 2 * nt_max);  // [cap] {depth bits, row}
+  uint16_t* tl = reinterpret_cast<uint16_t*>(stage + cap);        // [cap] band tile of the staged entry
+  __shared__ uint32_t wsum[BIN_THREADS / 64];
+  const int c = blockIdx.y, g = blockIdx.x / R, r = blockIdx.x - g * R;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ty0 = (int)((int64_t)r * tile_h / R), ty1 = (int)((int64_t)(r + 1) * tile_h / R);
+  const int t0 = ty0 * tile_w, nt = (ty1 - ty0) * tile_w;
+  if (nt == 0) return;
+  const int s0 = g * G, s1 = min(n_slices, s0 + G);
+  const int32_t* orow = offsets + (int64_t)c * T + t0;
+  const int32_t* crow = tile_counts + (int64_t)c * T + t0;
+  const int K = (nt + BIN_THREADS - 1) / BIN_THREADS;  // consecutive tiles per thread in the scan
+  int sa = s0;
+  while (sa < s1) {
+    const uint32_t* ra = table + ((int64_t)c * n_slices + sa) * T + t0;
+    int sb = s1;
+    uint32_t total;
+    for (;;) {
+      // pairs per tile of slices [sa, sb): difference of the prefix rows (past the last slice: the tile's total)
+      const uint32_t* rb = sb < n_slices ? table + ((int64_t)c * n_slices + sb) * T + t0 : nullptr;
+      for (int t = tid; t < nt; t += BIN_THREADS) lcur[t] = (rb ? rb[t] : (uint32_t)crow[t]) - ra[t];
+      __syncthreads();
+      uint32_t mine = 0;
+      const int k0 = tid * K, k1 = min(nt, k0 + K);
+      for (int t = k0; t < k1; ++t) mine += lcur[t];
+      uint32_t incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
       }
-      if (cntg > 0 && cntg <= BIN_COOP) {
-        if (CULL && masked) {
-          const int w = x1 - x0;
-          const unsigned long long wmask = w < 64 ? (1ull << w) - 1ull : ~0ull;
-          int base = (y0 - ty0) * tile_w + x0;
-          for (int rr = 0; rr < rows; ++rr, base += tile_w) {
-            unsigned long long rb = m & wmask;
-            m >>= (w & 63);
-            while (rb) {
-              const int j = __ffsll((long long)rb) - 1;
-              rb &= rb - 1;
-              const uint32_t pos = atomicAdd(&cur[base + j], 1u);
-              pairs[pos] = make_uint2(dbits, idx);
-            }
-          }
-        } else {
-          int tj = x0, trow0 = (y0 - ty0) * tile_w;
-          for (int t = 0; t < cntg; ++t) {
-            const uint32_t pos = atomicAdd(&cur[trow0 + tj], 1u);
-            pairs[pos] = make_uint2(dbits, idx);
-            if (++tj == x1) { tj = x0; trow0 += tile_w; }
-          }
-        }
+      if (lane == 63) wsum[wave] = incl;
+      __syncthreads();
+      uint32_t before = 0, all = 0;
+#pragma unroll
+      for (int w = 0; w < BIN_THREADS / 64; ++w) {
+        if (w < wave) before += wsum[w];
+        all += wsum[w];
       }
-      unsigned long long big = __ballot(cntg > BIN_COOP);
-      while (big) {
-        const int src = __ffsll((long long)big) - 1;
-        big &= big - 1;
-        const int b_cnt = __shfl(cntg, src), b_x0 = __shfl(x0, src), b_y0 = __shfl(y0, src) - ty0;
-        const int b_w = __shfl(x1, src) - b_x0;
-        const uint32_t b_d = __shfl(dbits, src), b_idx = __shfl(idx, src);
-        if (CULL && __shfl((int)masked, src)) {
-          const uint32_t mlo = __shfl((uint32_t)m, src), mhi = __shfl((uint32_t)(m >> 32), src);
-          const unsigned long long bm = ((unsigned long long)mhi << 32) | mlo;
-          if ((bm >> lane) & 1ull) {
-            const int ti = b_y0 + lane / b_w, tj = b_x0 + lane % b_w;
-            const uint32_t pos = atomicAdd(&cur[ti * tile_w + tj], 1u);
-            pairs[pos] = make_uint2(b_d, b_idx);
-          }
-          continue;
+      total = all;
+      if (total <= (uint32_t)cap || sb - sa == 1) {
+        uint32_t run = before + incl - mine;
+        for (int t = k0; t < k1; ++t) {
+          const uint32_t v = lcur[t];
+          lcur[t] = run;
+          run += v;
         }
-        for (int t = lane; t < b_cnt; t += 64) {
-          const int ti = b_y0 + t / b_w, tj = b_x0 + t % b_w;
-          const uint32_t pos = atomicAdd(&cur[ti * tile_w + tj], 1u);
-          pairs[pos] = make_uint2(b_d, b_idx);
-        }
+        break;
       }
+      sb = sa + (sb - sa) / 2;
+      __syncthreads();  // (wsum and lcur are rewritten by the next attempt)
     }
+    __syncthreads();
+    const bool direct = total > (uint32_t)cap;  // one slice with more pairs than the staging area holds
+    for (int t = tid; t < nt; t += BIN_THREADS) {
+      const uint32_t gpos = (uint32_t)orow[t] + ra[t];
+      if (direct) lcur[t] = gpos; else gdelta[t] = gpos - lcur[t];
+    }
+    __syncthreads();
+    const int32_t* cnt_row = vis_cnt + (int64_t)c * n_slices;
+    const uint4* list_row = vis_list + (int64_t)c * n_slices * seg_cap;
+    const uint2* mask_row = CULL ? vis_mask + (int64_t)c * n_slices * seg_cap : nullptr;
+    if (direct)
+      region_walk<CULL>(sa, sb, cnt_row, list_row, mask_row, seg_cap, ty0, ty1, tile_w,
+                        [&](int t, uint32_t dbits, uint32_t idx) {
+                          const uint32_t pos = atomicAdd(&lcur[t], 1u);
+                          pairs[pos] = make_uint2(dbits, idx);
+                        });
+    else
+      region_walk<CULL>(sa, sb, cnt_row, list_row, mask_row, seg_cap, ty0, ty1, tile_w,
+                        [&](int t, uint32_t dbits, uint32_t idx) {
+                          const uint32_t pos = atomicAdd(&lcur[t], 1u);
+                          stage[pos] = make_uint2(dbits, idx);
+                          tl[pos] = (uint16_t)t;
+                        });
+    __syncthreads();
+    if (!direct)
+      for (uint32_t e = tid; e < total; e += BIN_THREADS) pairs[gdelta[tl[e]] + e] = stage[e];
+    __syncthreads();
+    sa = sb;
   }
 }
 
@@ -960,6 +1120,9 @@ static inline int bin_ilog2_floor(int64_t v) {
 #ifndef GS_TS_G3
 #define GS_TS_G3 14
 #endif
+#ifndef GS_SCATTER_LDS  // LDS bytes of the staged region scatter (cursors + staging area), one workgroup per CU
+#define GS_SCATTER_LDS (163840 - 256)
+#endif
 static int bin_check(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, int32_t n_slices) {
   if (C < 1 || N < 0 || tile_w < 1 || tile_h < 1 || n_slices < 1) return GS_ERR_INVALID_ARG;
   if ((int64_t)tile_w * tile_h > gs::BIN_MAX_TILES) return GS_ERR_UNSUPPORTED;
@@ -1038,8 +1201,8 @@ extern "C" int gs_isect_bin_scatter(int32_t C, int32_t N, int32_t tile_w, int32_
 extern "C" int gs_isect_bin_scatter_regions(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, int32_t n_slices,
                                             int32_t slices_per_group, int32_t n_regions, const uint64_t* vis_list,
                                             const int32_t* vis_counts, const uint64_t* vis_masks,
-                                            const uint32_t* table, const int32_t* isect_offsets, uint64_t* pairs,
-                                            void* stream) {
+                                            const uint32_t* table, const int32_t* isect_offsets,
+                                            const int32_t* tile_counts, uint64_t* pairs, void* stream) {
   int st = bin_check(C, N, tile_w, tile_h, n_slices);
   if (st != GS_OK) return st;
   if (slices_per_group < 1 || n_regions < 1 || n_regions > 65535) return GS_ERR_INVALID_ARG;
@@ -1053,6 +1216,31 @@ extern "C" int gs_isect_bin_scatter_regions(int32_t C, int32_t N, int32_t tile_w
   const int band_rows = (int)gs::ceil_div(tile_h, n_regions) + 1;
   const dim3 grid((unsigned)(groups * n_regions), (unsigned)C);
   const size_t lds = (size_t)band_rows * tile_w * sizeof(uint32_t);
+  // staged through LDS when the list lengths are at hand and the band's cursors leave room for a useful staging area
+  const int64_t nt_max = (int64_t)band_rows * tile_w;
+  const int64_t cap = ((GS_SCATTER_LDS - 8 * nt_max) / 10) & ~(int64_t)63;
+  if (tile_counts && cap >= 2048) {
+    const size_t lds_staged = (size_t)(8 * nt_max + 10 * cap);
+    const void* fn = vis_masks ? (const void*)gs::isect_region_scatter_staged_kernel<true>
+                               : (const void*)gs::isect_region_scatter_staged_kernel<false>;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged);
+    if (e != hipSuccess) return (int)e;
+    if (vis_masks)
+      hipLaunchKernelGGL(gs::isect_region_scatter_staged_kernel<true>, grid, dim3(gs::BIN_THREADS), lds_staged,
+                         (hipStream_t)stream, tile_w, tile_h, T, n_slices, slices_per_group, n_regions,
+                         bin_slice_rows(N, n_slices), (int32_t)nt_max, (int32_t)cap,
+                         reinterpret_cast<const uint4*>(vis_list), vis_counts,
+                         reinterpret_cast<const uint2*>(vis_masks), table, isect_offsets, tile_counts,
+                         reinterpret_cast<uint2*>(pairs));
+    else
+      hipLaunchKernelGGL(gs::isect_region_scatter_staged_kernel<false>, grid, dim3(gs::BIN_THREADS), lds_staged,
+                         (hipStream_t)stream, tile_w, tile_h, T, n_slices, slices_per_group, n_regions,
+                         bin_slice_rows(N, n_slices), (int32_t)nt_max, (int32_t)cap,
+                         reinterpret_cast<const uint4*>(vis_list), vis_counts, (const uint2*)nullptr, table,
+                         isect_offsets, tile_counts, reinterpret_cast<uint2*>(pairs));
+    GS_CHECK_LAUNCH();
+    return GS_OK;
+  }
   if (vis_masks)
     hipLaunchKernelGGL(gs::isect_region_scatter_kernel<true>, grid, dim3(gs::BIN_THREADS), lds, (hipStream_t)stream,
                        tile_w, tile_h, T, n_slices, slices_per_group, n_regions, bin_slice_rows(N, n_slices),

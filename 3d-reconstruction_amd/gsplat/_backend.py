@@ -78,7 +78,7 @@ _SIGNATURES = {
                                [c_int32, _P, _P, _P, _P, _P, _P]),
     "gs_isect_bin_offsets": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P]),
     "gs_isect_bin_scatter": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, c_int32, _P, _P, _P, _P]),
-    "gs_isect_bin_scatter_regions": (ctypes.c_int, [c_int32] * 7 + [_P] * 7),
+    "gs_isect_bin_scatter_regions": (ctypes.c_int, [c_int32] * 7 + [_P] * 8),
     "gs_isect_tile_sort": (ctypes.c_int, [c_int32, c_int32, c_int32, _P, c_int64, _P, _P, _P, _P, _P, _P]),
     "gs_radix_sort_workspace_bytes": (c_int64, [c_int64]),
     "gs_radix_sort_pairs_u64_u32_ex": (ctypes.c_int, [c_int64, _P, c_int32, c_int32, _P, _P, _P, _P, _P, c_int64, POINTER(c_int32), _P]),

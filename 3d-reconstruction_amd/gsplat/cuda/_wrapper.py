@@ -457,7 +457,7 @@ def _host_scalar() -> Tensor:
 
 
 SLICES_TOTAL = 512        # count-pass workgroups over all cameras (row slices x cameras)
-SCATTER_REGIONS = 2       # bands of tile rows in the region scatter
+SCATTER_REGIONS = 0       # bands of tile rows in the region scatter; 0: chosen per shape (see isect_tiles_binned)
 SCATTER_WORKGROUPS = 256  # ... and about this many scatter workgroups (slices are grouped to get there)
 FUSED_LAUNCHES = True  # the composite entry points (one FFI call per launch sequence); False: one call per kernel
 _bin_max_tiles = []
@@ -470,6 +470,7 @@ def bin_max_tiles() -> int:
     return _bin_max_tiles[0]
 
 
+STAGED_SCATTER = True  # region scatter sorts a workgroup's pairs by tile in LDS and writes whole runs (False: 8-B stores)
 REGION_SCATTER = True  # scatter from the count pass's visible lists by tile band (False: by row slice, from the records)
 # rasterization() builds CULLED tile lists when it renders with gradients or packed (gs_isect_bin_count, "Culled
 # lists"): pairs whose splat cannot reach alpha 1/255 anywhere on the tile are left out.  No rendered value or gradient
@@ -502,9 +503,16 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
     counts = torch.empty(C * T, device=dev, dtype=torch.int32)
     offsets = torch.empty(C, tile_height, tile_width, device=dev, dtype=torch.int32)
     total = torch.empty(1, device=dev, dtype=torch.int64)
-    # region scatter: two bands of tile rows x groups of slices, about one 1024-thread workgroup per CU (measured best
-    # of 1..32 bands x 1..32 slices per group at 5 x 1242x375 and 1 x 1920x1280: DESIGN.md section 6)
-    regions = min(SCATTER_REGIONS, tile_height)
+    # region scatter: bands of tile rows x groups of slices, about one 1024-thread workgroup per CU.  With direct 8-B
+    # stores two bands measured best (of 1..32 bands x 1..32 slices per group at 5 x 1242x375 and 1 x 1920x1280:
+    # DESIGN.md section 6);
+    # staged through LDS (STAGED_SCATTER): bands of 2 000-5 000 tiles measured best -- one band per camera at 1242x375
+    # (1 872 tiles: 42.8 us against 53.8 / 76.2 with two / four bands), two at 1920x1280 (9 600 tiles: 94 us against 122
+    # with one band, 116 / 121 with three / four); profiles/r02_ab_runs.txt item 12
+    if SCATTER_REGIONS:
+        regions = min(SCATTER_REGIONS, tile_height)
+    else:
+        regions = min(max(1, T // 4000), tile_height) if STAGED_SCATTER else min(2, tile_height)
     group = max(1, -(-(n_slices * C * regions) // SCATTER_WORKGROUPS))
     vis_list = vis_cnt = vis_masks = None
     if REGION_SCATTER:
@@ -559,6 +567,10 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
         if while_counting is not None:
             while_counting()
         n_isects = int(total.item())  # the one host sync of the pipeline (gsplat has the same one)
+        if want_order:  # (as the fused path: no front to sort first without a tile above 1024 entries)
+            sc_host = (ctypes.c_int32 * 3)(*n_long.tolist())
+            if sc_host[1] == 0:
+                use_front = False
     isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64)
     flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
     if n_isects == 0:
@@ -569,7 +581,8 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
             B.check(lib.gs_isect_bin_build(C, N, tile_width, tile_height, n_slices, group, regions, B.ptr(vis_list),
                                            B.ptr(vis_cnt), B.ptr(vis_masks), B.ptr(table), B.ptr(offsets), n_isects,
                                            B.ptr(order), B.ptr(n_long), FRONT_K_TARGET if use_front else 0,
-                                           B.ptr(pairs), B.ptr(isect_ids), B.ptr(flatten_ids), B.ptr(counts),
+                                           B.ptr(pairs), B.ptr(isect_ids), B.ptr(flatten_ids),
+                                           B.ptr(counts) if (STAGED_SCATTER or use_front) else None,
                                            ctypes.addressof(sc_host) if sc_host is not None else None, st),
                     "gs_isect_bin_build")
         if use_front:
@@ -582,22 +595,27 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
         if vis_list is not None:
             B.check(lib.gs_isect_bin_scatter_regions(C, N, tile_width, tile_height, n_slices, group, regions,
                                                      B.ptr(vis_list), B.ptr(vis_cnt), B.ptr(vis_masks), B.ptr(table),
-                                                     B.ptr(offsets), B.ptr(pairs), st), "gs_isect_bin_scatter_regions")
+                                                     B.ptr(offsets), B.ptr(counts) if STAGED_SCATTER else None,
+                                                     B.ptr(pairs), st), "gs_isect_bin_scatter_regions")
         else:
             B.check(lib.gs_isect_bin_scatter(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
                                              n_slices, B.ptr(table), B.ptr(offsets), B.ptr(pairs), st),
                     "gs_isect_bin_scatter")
+    sc_ptr = ctypes.addressof(sc_host) if sc_host is not None else None
     if use_front:
         # `counts` (the list lengths) becomes sorted_counts: the front kernel overwrites the long tiles' entries
         with B.device_guard(dev), B.timed("gs_isect_tile_sort", dev):
-            B.check(lib.gs_isect_tile_sort_front(C, tile_width, tile_height, B.ptr(offsets), n_isects, B.ptr(order),
-                                                 B.ptr(n_long), FRONT_K_TARGET, B.ptr(pairs), B.ptr(isect_ids),
-                                                 B.ptr(flatten_ids), B.ptr(counts), st), "gs_isect_tile_sort_front")
+            B.check(lib.gs_isect_tile_sort_front_ex(C, tile_width, tile_height, B.ptr(offsets), n_isects, B.ptr(order),
+                                                    B.ptr(n_long), FRONT_K_TARGET, B.ptr(pairs), B.ptr(isect_ids),
+                                                    B.ptr(flatten_ids), B.ptr(counts), sc_ptr, st),
+                    "gs_isect_tile_sort_front")
         fs = FrontSort((C, tile_width, tile_height), offsets, order, n_long, pairs, isect_ids, flatten_ids, counts)
+        fs.size_classes_host = sc_host
         return isect_ids, flatten_ids, offsets, order, fs
     with B.device_guard(dev), B.timed("gs_isect_tile_sort", dev):
-        B.check(lib.gs_isect_tile_sort(C, tile_width, tile_height, B.ptr(offsets), n_isects, B.ptr(order), B.ptr(n_long),
-                                       B.ptr(pairs), B.ptr(isect_ids), B.ptr(flatten_ids), st), "gs_isect_tile_sort")
+        B.check(lib.gs_isect_tile_sort_ex(C, tile_width, tile_height, B.ptr(offsets), n_isects, B.ptr(order),
+                                          B.ptr(n_long), B.ptr(pairs), B.ptr(isect_ids), B.ptr(flatten_ids), sc_ptr, st),
+                "gs_isect_tile_sort")
     return isect_ids, flatten_ids, offsets, order, None
 
 

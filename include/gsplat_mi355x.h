@@ -266,11 +266,15 @@ int gs_isect_bin_scatter(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, c
                          const int32_t* isect_offsets, uint64_t* pairs, void* stream);
 /* Same result as gs_isect_bin_scatter up to the order inside a tile segment (which the sort fixes), from the visible
  * lists of the count pass: a workgroup owns a band of tile rows (n_regions bands) and slices_per_group consecutive
- * slices, so the runs it writes into a tile segment are slices_per_group * n_regions times as long. */
+ * slices, so the runs it writes into a tile segment are slices_per_group * n_regions times as long.
+ * tile_counts (gs_isect_bin_offsets' output, or NULL): with the list lengths at hand the workgroup sorts its pairs by
+ * tile in LDS first and writes every tile's run in one piece (consecutive lanes, consecutive entries) instead of one
+ * 8-byte store per pair; NULL, or a band whose cursors leave no room for a staging area, takes the direct stores. */
 int gs_isect_bin_scatter_regions(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, int32_t n_slices,
                                  int32_t slices_per_group, int32_t n_regions, const uint64_t* vis_list,
                                  const int32_t* vis_counts, const uint64_t* vis_masks /* or NULL: see above */,
-                                 const uint32_t* table, const int32_t* isect_offsets, uint64_t* pairs, void* stream);
+                                 const uint32_t* table, const int32_t* isect_offsets,
+                                 const int32_t* tile_counts /* or NULL */, uint64_t* pairs, void* stream);
 int gs_isect_tile_sort(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets, int64_t n_isects,
                        const int32_t* tile_order /* launch order from gs_raster_tile_order, or NULL */,
                        const int32_t* size_classes /* its size_classes output (device int32[3]), or NULL */,
@@ -358,8 +362,9 @@ int gs_raster_tile_order(int32_t n_tiles, const int32_t* isect_offsets, int64_t 
  *                            return *n_isects_host is valid (the pipeline's one host synchronisation; pinned memory
  *                            avoids a staging copy).  With synchronize == 0 the caller does its remaining host work
  *                            first and then calls gs_stream_synchronize(stream) before reading *n_isects_host.
- *   gs_isect_bin_build     = gs_isect_bin_scatter_regions + gs_isect_tile_sort_front (k_target > 0) or
- *                            gs_isect_tile_sort (k_target == 0; sorted_counts unused).
+ *   gs_isect_bin_build     = gs_isect_bin_scatter_regions (tile_counts = sorted_counts as it arrives: the list
+ *                            lengths, or NULL) + gs_isect_tile_sort_front (k_target > 0; sorted_counts must then hold
+ *                            the list lengths) or gs_isect_tile_sort (k_target == 0).
  *   gs_rasterize_fwd_front = gs_rasterize_fwd pass 0 + gs_isect_tile_sort_redo + gs_rasterize_fwd pass 1.             */
 int gs_isect_bin_prepare(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, const float* splats,
                          const int32_t* tiles_per_gauss, int32_t n_slices, uint32_t* table, uint64_t* vis_list,

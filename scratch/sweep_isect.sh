@@ -1,7 +1,7 @@
 #!/bin/bash
 # launch-shape sweep of the count / scatter passes (env overrides read by bench.py)
 run() {
-  out=$(env "$@" timeout -k 10 120 python3 bench.py --no-cpu-baseline --steps 20 2>/dev/null) || { echo "$* FAILED"; exit 1; }
+  out=$(env "$@" timeout -k 10 120 python3 bench.py --no-cpu-baseline --steps 20 $EXTRA 2>/dev/null) || { echo "$* FAILED"; exit 1; }
   python3 - "$*" <<PY
 import json,sys
 d=json.loads('''$out'''.strip().splitlines()[-1]); k=d["kernels_ms"]

@@ -195,7 +195,7 @@ def test_entry_points_reject_bad_arguments_before_any_launch():
     too_many = L.gs_isect_bin_max_tiles() + 1
     assert L.gs_isect_bin_count(1, 10, too_many, 1, P, P, 1, P, None, None, None, 0, None) == UNSUPPORTED
     assert L.gs_isect_bin_count(1, 10, 4, 4, P, P, 1, P, None, None, P, 16, None) == INVALID  # tile masks without the lists
-    assert L.gs_isect_bin_scatter_regions(1, 10, 4, 4, 1, 0, 2, P, P, None, P, P, P, None) == INVALID  # slices_per_group < 1
+    assert L.gs_isect_bin_scatter_regions(1, 10, 4, 4, 1, 0, 2, P, P, None, P, P, None, P, None) == INVALID  # slices_per_group < 1
     # composite launches: rejected before their first launch
     assert L.gs_isect_bin_prepare(1, 10, 4, 4, P, P, 1, P, P, P, None, 0, P, P, P, P, P, None, None, None, 1, None) == INVALID  # no host scalar
     assert L.gs_isect_bin_prepare(1, 10, too_many, 1, P, P, 1, P, P, P, None, 0, P, P, P, P, P, None, P, None, 1, None) == UNSUPPORTED

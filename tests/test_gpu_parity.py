@@ -88,14 +88,14 @@ def test_scan_and_radix_sort(gpu_device):
         assert np.array_equal(k.cpu().numpy(), keys[order]), (n, bits)
 
 
-def _synthetic_records(rng, C, N, TW, TH, hot_tile_rows, depth_levels, dev):
+def _synthetic_records(rng, C, N, TW, TH, hot_tile_rows, depth_levels, dev, box=4):
     """Splat records carrying only what the intersection stage reads: depth [10] and the tile box [13], [14]."""
     from gsplat import _backend as B
 
     x0 = rng.integers(0, TW, size=(C, N))
     y0 = rng.integers(0, TH, size=(C, N))
-    w = rng.integers(1, 4, size=(C, N))
-    h = rng.integers(1, 4, size=(C, N))
+    w = rng.integers(1, box, size=(C, N))
+    h = rng.integers(1, box, size=(C, N))
     big = rng.random((C, N)) < 0.01  # a few boxes above the cooperative threshold (> 16 tiles)
     w = np.where(big, rng.integers(5, max(6, TW), size=(C, N)), w)
     h = np.where(big, rng.integers(4, max(5, TH), size=(C, N)), h)
@@ -155,6 +155,31 @@ def test_binned_isect_matches_stable_sort(gpu_device, C, N, TW, TH, hot, levels)
     assert np.array_equal(k2.cpu().numpy(), keys)
     assert np.array_equal(f2.cpu().numpy(), ids)
     assert np.array_equal(isect_offset_encode(k2, C, TW, TH).cpu().numpy(), offsets)
+
+
+@pytest.mark.parametrize("staged,workgroups,regions,box", [(False, 256, 0, 4), (True, 256, 0, 4), (True, 2, 0, 4),
+                                                          (True, 3, 2, 4), (True, 256, 0, 9), (True, 2, 0, 9)])
+def test_binned_isect_scatter_modes(gpu_device, staged, workgroups, regions, box):
+    """The region scatter with direct 8-byte stores and staged through LDS (gs_isect_bin_scatter_regions, tile_counts):
+    one slice per workgroup, groups of slices whose pairs exceed the staging area (the chunk is halved until it fits)
+    and slices that exceed it alone (scattered directly) all give numpy's stable sort, bit for bit."""
+    from gsplat.cuda import _wrapper as Wm
+
+    rng = np.random.default_rng(77)
+    C, N, TW, TH = 1, 40_000, 60, 34
+    rec, tiles, keys, ids, offsets = _synthetic_records(rng, C, N, TW, TH, 0, 50, gpu_device, box=box)
+    saved = (Wm.STAGED_SCATTER, Wm.SCATTER_WORKGROUPS, Wm.SCATTER_REGIONS)
+    try:
+        Wm.STAGED_SCATTER, Wm.SCATTER_WORKGROUPS, Wm.SCATTER_REGIONS = staged, workgroups, regions
+        k, f, o, _, _ = Wm.isect_tiles_binned(rec, tiles, TW, TH)
+    finally:
+        Wm.STAGED_SCATTER, Wm.SCATTER_WORKGROUPS, Wm.SCATTER_REGIONS = saved
+    n_slices = -(-N // 4096)
+    print(f"[scatter] staged={staged} workgroups={workgroups} box<{box}: {keys.size} pairs over {n_slices} slices "
+          f"({keys.size // n_slices} per slice)")
+    assert np.array_equal(k.cpu().numpy(), keys)
+    assert np.array_equal(f.cpu().numpy(), ids)
+    assert np.array_equal(o.cpu().numpy(), offsets)
 
 
 def test_binned_isect_empty(gpu_device):
