@@ -26,7 +26,7 @@ SIMDS = 256 * 4
 KERNELS = {
     "gs_projection_fwd": "projection_fwd_kernel", "gs_projection_bwd": "projection_bwd_kernel",
     "gs_sh_bwd_cams": "sh_bwd_cams_kernel",
-    "gs_isect_bin_count": "isect_bin_kernel<false, true>", "gs_isect_bin_scatter": "isect_region_scatter_kernel<true>",
+    "gs_isect_bin_count": "isect_bin_kernel<false, true>", "gs_isect_bin_scatter": "isect_region_scatter_staged_kernel<true>",
     "gs_isect_tile_sort_front": "tile_sort_front_kernel", "gs_rasterize_fwd": "rasterize_fwd_kernel",
     "gs_rasterize_bwd": "rasterize_bwd_kernel",
 }

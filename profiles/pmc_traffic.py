@@ -29,7 +29,7 @@ KERNELS = {  # bench.py entry-point label -> substring(s) of the HIP kernel name
     "gs_projection_fwd": ["gs::projection_fwd_kernel"],
     "gs_projection_bwd": ["gs::projection_bwd_kernel", "gs::sh_bwd_packed_kernel"],
     "gs_isect_bin_count": ["gs::isect_bin_kernel<false, true>"],
-    "gs_isect_bin_scatter": ["gs::isect_region_scatter_kernel<true>"],
+    "gs_isect_bin_scatter": ["gs::isect_region_scatter_staged_kernel<true>"],
     "gs_isect_bin_offsets": ["gs::bin_slice_prefix_kernel", "gs::bin_offsets_kernel"],
     "gs_isect_tile_sort": ["gs::tile_sort_kernel", "gs::tile_sort_front_kernel"],
     "gs_rasterize_fwd": ["gs::rasterize_fwd_kernel"],
