@@ -1,4 +1,5 @@
 // Version / error-string entry points of libgsplat_mi355x.so.
+#include <chrono>
 #include "gs_common.hpp"
 
 extern "C" int gs_version(void) { return 100; }  // 0.1.0 (round 1)
@@ -9,6 +10,7 @@ extern "C" const char* gs_error_string(int status) {
     case GS_ERR_INVALID_ARG: return "gsplat_mi355x: invalid argument";
     case GS_ERR_UNSUPPORTED: return "gsplat_mi355x: unsupported configuration";
     case GS_ERR_WORKSPACE: return "gsplat_mi355x: workspace too small";
+    case GS_ERR_NOT_POSTED: return "gsplat_mi355x: the kernels did not post their results";
     default: break;
   }
   if (status > 0) return hipGetErrorString((hipError_t)status);
@@ -38,21 +40,35 @@ extern "C" int gs_isect_bin_prepare(int32_t C, int32_t N, int32_t tile_w, int32_
                                     int32_t* tile_counts, int32_t* isect_offsets, int64_t* total, int32_t* tile_order,
                                     int32_t* size_classes, int32_t* redo_flags, int64_t* n_isects_host,
                                     int32_t* size_classes_host, int32_t synchronize, void* stream) {
-  if (!n_isects_host || !total) return GS_ERR_INVALID_ARG;
+  if (!n_isects_host || !total || synchronize < 0 || synchronize > 2) return GS_ERR_INVALID_ARG;
+  const bool posted = synchronize == 2;  // the kernels write n_isects / the size classes into the host slot themselves
   int st = gs_isect_bin_count(C, N, tile_w, tile_h, splats, tiles_per_gauss, n_slices, table, vis_list, vis_counts,
                               vis_masks, tile_size, stream);
   if (st != GS_OK) return st;
-  st = gs_isect_bin_offsets(C, tile_w, tile_h, n_slices, table, tile_counts, isect_offsets, total, stream);
-  if (st != GS_OK) return st;
   hipStream_t s = (hipStream_t)stream;
-  // the one host synchronisation of the pipeline (gsplat has the same one): n_isects sizes the arrays that follow
-  hipError_t e = hipMemcpyAsync(n_isects_host, total, sizeof(int64_t), hipMemcpyDeviceToHost, s);
-  if (e != hipSuccess) return (int)e;
   const int32_t n_tiles = C * tile_w * tile_h;
+  hipError_t e;
+  if (posted) {
+    // slot = sentinel until the kernel's store lands (the launches below order these host stores before the kernels)
+    __atomic_store_n(n_isects_host, (int64_t)-1, __ATOMIC_RELAXED);
+    if (tile_order && size_classes_host && size_classes)
+      for (int i = 0; i < 3; ++i) __atomic_store_n(&size_classes_host[i], (int32_t)-1, __ATOMIC_RELAXED);
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  }
+  st = gs_isect_bin_offsets_post(C, tile_w, tile_h, n_slices, table, tile_counts, isect_offsets, total,
+                                 posted ? n_isects_host : nullptr, stream);
+  if (st != GS_OK) return st;
+  if (!posted) {
+    // the one host synchronisation of the pipeline (gsplat has the same one): n_isects sizes the arrays that follow
+    e = hipMemcpyAsync(n_isects_host, total, sizeof(int64_t), hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return (int)e;
+  }
   if (tile_order) {
-    st = gs_raster_tile_order(n_tiles, nullptr, 0, tile_counts, tile_order, size_classes, stream);
+    const bool want_classes = size_classes_host && size_classes;
+    st = gs_raster_tile_order_post(n_tiles, nullptr, 0, tile_counts, tile_order, size_classes,
+                                   (posted && want_classes) ? size_classes_host : nullptr, stream);
     if (st != GS_OK) return st;
-    if (size_classes_host && size_classes) {  // lets the host skip the launches of size classes that hold no tile
+    if (!posted && want_classes) {  // lets the host skip the launches of size classes that hold no tile
       e = hipMemcpyAsync(size_classes_host, size_classes, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
       if (e != hipSuccess) return (int)e;
     }
@@ -61,9 +77,47 @@ extern "C" int gs_isect_bin_prepare(int32_t C, int32_t N, int32_t tile_w, int32_
     e = hipMemsetAsync(redo_flags, 0, ((size_t)n_tiles + 1) * sizeof(int32_t), s);
     if (e != hipSuccess) return (int)e;
   }
-  if (!synchronize) return GS_OK;
+  if (synchronize != 1) return GS_OK;
   e = hipStreamSynchronize(s);
   return e == hipSuccess ? GS_OK : (int)e;
+}
+
+// ---- host slots the kernels post into (gs_isect_bin_prepare with synchronize == 2)
+extern "C" int gs_host_post_alloc(void** slot, int64_t bytes) {
+  if (!slot || bytes < 1) return GS_ERR_INVALID_ARG;
+  // coherent (fine-grained) pinned host memory mapped into the device's address space: a system-scope store from a
+  // kernel is visible to the polling host while the kernel is still running
+  const hipError_t e = hipHostMalloc(slot, (size_t)bytes, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent);
+  return e == hipSuccess ? GS_OK : (int)e;
+}
+
+extern "C" int gs_host_post_free(void* slot) {
+  const hipError_t e = hipHostFree(slot);
+  return e == hipSuccess ? GS_OK : (int)e;
+}
+
+extern "C" int gs_host_post_wait(const int64_t* n_isects_host, const int32_t* size_classes_host, int32_t timeout_ms,
+                                 void* stream) {
+  if (!n_isects_host || timeout_ms < 0) return GS_ERR_INVALID_ARG;
+  auto ready = [&]() {
+    if (__atomic_load_n(n_isects_host, __ATOMIC_ACQUIRE) == (int64_t)-1) return false;
+    if (size_classes_host)
+      for (int i = 0; i < 3; ++i)
+        if (__atomic_load_n(&size_classes_host[i], __ATOMIC_ACQUIRE) == (int32_t)-1) return false;
+    return true;
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spin = 0; !ready(); ++spin) {
+    __builtin_ia32_pause();
+    if ((spin & 1023u) == 1023u &&
+        std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms)) {
+      // not posted in time: let the stream finish (a failed launch surfaces here) and look once more
+      const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+      if (e != hipSuccess) return (int)e;
+      return ready() ? GS_OK : GS_ERR_NOT_POSTED;
+    }
+  }
+  return GS_OK;
 }
 
 extern "C" int gs_stream_synchronize(void* stream) {

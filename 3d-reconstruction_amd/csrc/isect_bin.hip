@@ -557,7 +557,8 @@ __global__ __launch_bounds__(256) void bin_slice_prefix_kernel(int32_t C, int32_
 
 // single workgroup: exclusive scan of the per-tile totals -> offsets, grand total -> *total
 __global__ __launch_bounds__(1024) void bin_offsets_kernel(int64_t n_tiles, const int32_t* __restrict__ counts,
-                                                           int32_t* __restrict__ offsets, int64_t* __restrict__ total) {
+                                                           int32_t* __restrict__ offsets, int64_t* __restrict__ total,
+                                                           int64_t* total_post) {
   __shared__ int64_t wsum[16];
   __shared__ int64_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -597,7 +598,11 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(int64_t n_tiles, cons
     if (tid == 0) carry_s += all;
     __syncthreads();
   }
-  if (tid == 0) *total = carry_s;
+  if (tid == 0) {
+    *total = carry_s;
+    // ... and straight into host memory the caller polls (gs_host_post_wait): no copy, no stream synchronisation
+    if (total_post) __hip_atomic_store(total_post, carry_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // ------------------------------------------------------------------------------------------ per-tile sort
@@ -1170,6 +1175,12 @@ extern "C" int gs_isect_bin_count(int32_t C, int32_t N, int32_t tile_w, int32_t 
 
 extern "C" int gs_isect_bin_offsets(int32_t C, int32_t tile_w, int32_t tile_h, int32_t n_slices, uint32_t* table,
                                     int32_t* tile_counts, int32_t* isect_offsets, int64_t* total, void* stream) {
+  return gs_isect_bin_offsets_post(C, tile_w, tile_h, n_slices, table, tile_counts, isect_offsets, total, nullptr, stream);
+}
+
+extern "C" int gs_isect_bin_offsets_post(int32_t C, int32_t tile_w, int32_t tile_h, int32_t n_slices, uint32_t* table,
+                                         int32_t* tile_counts, int32_t* isect_offsets, int64_t* total,
+                                         int64_t* total_post, void* stream) {
   if (C < 1 || tile_w < 1 || tile_h < 1 || n_slices < 1) return GS_ERR_INVALID_ARG;
   if (!table || !tile_counts || !isect_offsets || !total) return GS_ERR_INVALID_ARG;
   const int T = tile_w * tile_h;
@@ -1177,7 +1188,8 @@ extern "C" int gs_isect_bin_offsets(int32_t C, int32_t tile_w, int32_t tile_h, i
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(gs::bin_slice_prefix_kernel, dim3((unsigned)gs::ceil_div(n_tiles, 64)), dim3(256), 0, s, C, T,
                      n_slices, table, tile_counts);
-  hipLaunchKernelGGL(gs::bin_offsets_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_counts, isect_offsets, total);
+  hipLaunchKernelGGL(gs::bin_offsets_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_counts, isect_offsets, total,
+                     total_post);
   GS_CHECK_LAUNCH();
   return GS_OK;
 }

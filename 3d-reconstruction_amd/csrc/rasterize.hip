@@ -517,7 +517,8 @@ __global__ __launch_bounds__(64) void rasterize_bwd_kernel(
 template <int ITEMS>  // register-cached costs per thread; n_tiles <= 1024 * ITEMS
 __global__ __launch_bounds__(1024) void tile_order_kernel(int n_tiles, const int32_t* __restrict__ offsets,
                                                           int64_t n_isects, const int32_t* __restrict__ work,
-                                                          int32_t* __restrict__ order, int32_t* __restrict__ n_long) {
+                                                          int32_t* __restrict__ order, int32_t* __restrict__ n_long,
+                                                          int32_t* n_long_post) {
   __shared__ int red[16];
   __shared__ unsigned hist[1024];
   __shared__ unsigned wsum[16];
@@ -577,6 +578,11 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int n_tiles, const int
     if (tid == 256) n_long[0] = (int32_t)(before + incl - h);
     if (tid == 640) n_long[1] = (int32_t)(before + incl - h);
     if (tid == 832) n_long[2] = (int32_t)(before + incl - h);
+  }
+  if (n_long_post) {  // the same three values straight into host memory the caller polls (gs_host_post_wait)
+    const int slot = tid == 256 ? 0 : tid == 640 ? 1 : tid == 832 ? 2 : -1;
+    if (slot >= 0)
+      __hip_atomic_store(&n_long_post[slot], (int32_t)(before + incl - h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
 #pragma unroll
@@ -660,19 +666,28 @@ extern "C" int gs_rasterize_bwd(int32_t C, int32_t width, int32_t height, int32_
   return GS_OK;
 }
 
-extern "C" int gs_raster_tile_order(int32_t n_tiles, const int32_t* isect_offsets, int64_t n_isects,
-                                    const int32_t* tile_work, int32_t* tile_order, int32_t* n_long, void* stream) {
+extern "C" int gs_raster_tile_order_post(int32_t n_tiles, const int32_t* isect_offsets, int64_t n_isects,
+                                         const int32_t* tile_work, int32_t* tile_order, int32_t* n_long,
+                                         int32_t* n_long_post, void* stream) {
   if (n_tiles < 1 || n_isects < 0 || !tile_order) return GS_ERR_INVALID_ARG;
   if (!tile_work && !isect_offsets) return GS_ERR_INVALID_ARG;
+  if (n_long_post && !n_long) return GS_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
+#define GS_TO_ARGS n_tiles, isect_offsets, n_isects, tile_work, tile_order, n_long, n_long_post
   if (n_tiles <= 1024 * 10)
-    hipLaunchKernelGGL(gs::tile_order_kernel<10>, dim3(1), dim3(1024), 0, s, n_tiles, isect_offsets, n_isects, tile_work, tile_order, n_long);
+    hipLaunchKernelGGL(gs::tile_order_kernel<10>, dim3(1), dim3(1024), 0, s, GS_TO_ARGS);
   else if (n_tiles <= 1024 * 32)
-    hipLaunchKernelGGL(gs::tile_order_kernel<32>, dim3(1), dim3(1024), 0, s, n_tiles, isect_offsets, n_isects, tile_work, tile_order, n_long);
+    hipLaunchKernelGGL(gs::tile_order_kernel<32>, dim3(1), dim3(1024), 0, s, GS_TO_ARGS);
   else if (n_tiles <= 1024 * 128)
-    hipLaunchKernelGGL(gs::tile_order_kernel<128>, dim3(1), dim3(1024), 0, s, n_tiles, isect_offsets, n_isects, tile_work, tile_order, n_long);
+    hipLaunchKernelGGL(gs::tile_order_kernel<128>, dim3(1), dim3(1024), 0, s, GS_TO_ARGS);
   else
     return GS_ERR_UNSUPPORTED;
+#undef GS_TO_ARGS
   GS_CHECK_LAUNCH();
   return GS_OK;
+}
+
+extern "C" int gs_raster_tile_order(int32_t n_tiles, const int32_t* isect_offsets, int64_t n_isects,
+                                    const int32_t* tile_work, int32_t* tile_order, int32_t* n_long, void* stream) {
+  return gs_raster_tile_order_post(n_tiles, isect_offsets, n_isects, tile_work, tile_order, n_long, nullptr, stream);
 }

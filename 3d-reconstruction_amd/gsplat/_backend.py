@@ -67,6 +67,9 @@ _SIGNATURES = {
     "gs_isect_bin_prepare": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, c_int32, _P, _P, _P, _P, c_int32,
                                             _P, _P, _P, _P, _P, _P, _P, _P, c_int32, _P]),
     "gs_stream_synchronize": (ctypes.c_int, [_P]),
+    "gs_host_post_alloc": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), c_int64]),
+    "gs_host_post_free": (ctypes.c_int, [_P]),
+    "gs_host_post_wait": (ctypes.c_int, [_P, _P, c_int32, _P]),
     "gs_visibility_prefix": (ctypes.c_int, [c_int32, c_int32, _P, _P, _P, _P, c_int64, _P]),
     "gs_isect_bin_build": (ctypes.c_int, [c_int32] * 7 + [_P] * 5 + [c_int64, _P, _P, c_int32, _P, _P, _P, _P, _P, _P]),
     "gs_isect_tile_sort_ex": (ctypes.c_int, [c_int32, c_int32, c_int32, _P, c_int64, _P, _P, _P, _P, _P, _P, _P]),
@@ -77,6 +80,7 @@ _SIGNATURES = {
     "gs_rasterize_fwd_front": (ctypes.c_int, [c_int32] * 5 + [_P, _P, _P, c_int64, _P, c_int32] + [_P] * 8 +
                                [c_int32, _P, _P, _P, _P, _P, _P]),
     "gs_isect_bin_offsets": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P]),
+    "gs_isect_bin_offsets_post": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
     "gs_isect_bin_scatter": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, c_int32, _P, _P, _P, _P]),
     "gs_isect_bin_scatter_regions": (ctypes.c_int, [c_int32] * 7 + [_P] * 8),
     "gs_isect_tile_sort": (ctypes.c_int, [c_int32, c_int32, c_int32, _P, c_int64, _P, _P, _P, _P, _P, _P]),
@@ -91,6 +95,7 @@ _SIGNATURES = {
     "gs_rasterize_fwd": (ctypes.c_int, [c_int32] * 5 + [_P, _P, _P, c_int64, _P, c_int32, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, c_int32, _P, _P]),
     "gs_rasterize_bwd": (ctypes.c_int, [c_int32] * 5 + [_P, _P, _P, c_int64, _P, c_int32, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P]),
     "gs_raster_tile_order": (ctypes.c_int, [c_int32, _P, c_int64, _P, _P, _P, _P]),
+    "gs_raster_tile_order_post": (ctypes.c_int, [c_int32, _P, c_int64, _P, _P, _P, _P, _P]),
     "gs_densify_accumulate": (ctypes.c_int, [c_int32, c_int32, _P, _P, c_int64, c_float, c_float, c_float, c_int32,
                                              _P, _P, _P, _P]),
     "gs_rigid_transform_fwd": (ctypes.c_int, [c_int64, c_int32] + [_P] * 8),

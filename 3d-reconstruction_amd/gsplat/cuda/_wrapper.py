@@ -442,6 +442,8 @@ _ISECT_LABELS = ("gs_isect_bin_count", "gs_isect_bin_offsets", "gs_raster_tile_o
                  "gs_isect_tile_sort")
 _RASTER_FWD_LABELS = ("gs_rasterize_fwd", "gs_rasterize_fwd_redo", "gs_isect_tile_sort_redo")
 _host_scalars = {}
+_post_slots = {}
+POSTED_RESULTS = True  # n_isects and the size classes are posted into a polled host slot by the kernels themselves
 
 
 def _host_scalar() -> Tensor:
@@ -454,6 +456,22 @@ def _host_scalar() -> Tensor:
     if t is None:
         t = _host_scalars[key] = torch.zeros(3, dtype=torch.int64).pin_memory()  # n_isects | 3 x int32 size classes
     return t
+
+
+def _post_slot():
+    """(address, int64 view, int32 view) of this thread's host slot for posted results (include/gsplat_mi355x.h,
+    "posted results"): int64 n_isects | int32[3] size classes.  One per (thread, device context), kept for the life of
+    the process."""
+    import threading
+
+    key = threading.get_ident()
+    slot = _post_slots.get(key)
+    if slot is None:
+        p = ctypes.c_void_p()
+        B.check(B.lib().gs_host_post_alloc(ctypes.byref(p), 64), "gs_host_post_alloc")
+        slot = _post_slots[key] = (p.value, (ctypes.c_int64 * 1).from_address(p.value),
+                                   (ctypes.c_int32 * 3).from_address(p.value + 8))
+    return slot
 
 
 SLICES_TOTAL = 512        # count-pass workgroups over all cameras (row slices x cameras)
@@ -470,6 +488,8 @@ def bin_max_tiles() -> int:
     return _bin_max_tiles[0]
 
 
+# the front-first sort (+ redo pass) is used only when a tile list exceeds 2048 entries (size class 0; 1: 1024 entries)
+FRONT_FROM_CLASS = 0
 STAGED_SCATTER = True  # region scatter sorts a workgroup's pairs by tile in LDS and writes whole runs (False: 8-B stores)
 REGION_SCATTER = True  # scatter from the count pass's visible lists by tile band (False: by row slice, from the records)
 # rasterization() builds CULLED tile lists when it renders with gradients or packed (gs_isect_bin_count, "Culled
@@ -533,24 +553,37 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
         # launches")
         if use_front:
             redo_flags = torch.empty(C * T + 1, device=dev, dtype=torch.int32)
-        host_n = _host_scalar()
+        if POSTED_RESULTS:
+            slot_addr, slot_n, slot_sc = _post_slot()
+        else:
+            host_n = _host_scalar()
+            slot_addr = host_n.data_ptr()
         with B.device_guard(dev):
             B.check(lib.gs_isect_bin_prepare(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
                                              n_slices, B.ptr(table), B.ptr(vis_list), B.ptr(vis_cnt), B.ptr(vis_masks),
                                              int(cull_tile_size), B.ptr(counts), B.ptr(offsets), B.ptr(total),
-                                             B.ptr(order), B.ptr(n_long), B.ptr(redo_flags), host_n.data_ptr(),
-                                             host_n.data_ptr() + 8 if want_order else None, 0, st),
+                                             B.ptr(order), B.ptr(n_long), B.ptr(redo_flags), slot_addr,
+                                             slot_addr + 8 if want_order else None, 2 if POSTED_RESULTS else 0, st),
                     "gs_isect_bin_prepare")
             if while_counting is not None:
                 while_counting()
                 while_counting = None
-            B.check(lib.gs_stream_synchronize(st), "gs_stream_synchronize")
-        n_isects = int(host_n[0])
+            if POSTED_RESULTS:
+                # the kernels post n_isects / the size classes themselves: no copy kernels, no stream synchronisation,
+                # and the launches queued behind the producers (tile order, flag clears) still run while the host goes on
+                B.check(lib.gs_host_post_wait(slot_addr, slot_addr + 8 if want_order else None, 10_000, st),
+                        "gs_host_post_wait")
+                n_isects = int(slot_n[0])
+                classes = list(slot_sc) if want_order else None
+            else:
+                B.check(lib.gs_stream_synchronize(st), "gs_stream_synchronize")
+                n_isects = int(host_n[0])
+                classes = host_n.view(torch.int32)[2:5].tolist() if want_order else None
         if want_order:
             # host copy of the tile order's size classes: launches for classes that hold no tile are skipped, and
-            # without a tile above 1024 entries there is no front to sort first
-            sc_host = (ctypes.c_int32 * 3)(*host_n.view(torch.int32)[2:5].tolist())
-            if sc_host[1] == 0:
+            # without a tile above 2048 entries there is no front to sort first
+            sc_host = (ctypes.c_int32 * 3)(*classes)
+            if sc_host[FRONT_FROM_CLASS] == 0:
                 use_front = False
     else:
         with B.device_guard(dev), B.timed("gs_isect_bin_count", dev):
@@ -569,7 +602,7 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
         n_isects = int(total.item())  # the one host sync of the pipeline (gsplat has the same one)
         if want_order:  # (as the fused path: no front to sort first without a tile above 1024 entries)
             sc_host = (ctypes.c_int32 * 3)(*n_long.tolist())
-            if sc_host[1] == 0:
+            if sc_host[FRONT_FROM_CLASS] == 0:
                 use_front = False
     isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64)
     flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)

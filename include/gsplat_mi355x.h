@@ -52,6 +52,7 @@ extern "C" {
 #define GS_ERR_INVALID_ARG (-1)
 #define GS_ERR_UNSUPPORTED (-2)
 #define GS_ERR_WORKSPACE (-3)
+#define GS_ERR_NOT_POSTED (-4) /* gs_host_post_wait: the stream finished without the kernels having posted */
 
 /* colour source of gs_projection_fwd/_bwd */
 #define GS_COLOR_NONE 0 /* no colour input (render_mode "D"/"ED")                    */
@@ -261,6 +262,11 @@ int gs_isect_bin_count(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, con
                        int32_t* vis_counts, uint64_t* vis_masks, int32_t tile_size, void* stream);
 int gs_isect_bin_offsets(int32_t C, int32_t tile_w, int32_t tile_h, int32_t n_slices, uint32_t* table,
                          int32_t* tile_counts, int32_t* isect_offsets, int64_t* total, void* stream);
+/* ... the same, and the kernel also stores the total into *total_post (NULL: not), a host slot from
+ * gs_host_post_alloc that the caller polls with gs_host_post_wait ("posted results" below). */
+int gs_isect_bin_offsets_post(int32_t C, int32_t tile_w, int32_t tile_h, int32_t n_slices, uint32_t* table,
+                              int32_t* tile_counts, int32_t* isect_offsets, int64_t* total, int64_t* total_post,
+                              void* stream);
 int gs_isect_bin_scatter(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, const float* splats,
                          const int32_t* tiles_per_gauss, int32_t n_slices, const uint32_t* table,
                          const int32_t* isect_offsets, uint64_t* pairs, void* stream);
@@ -351,6 +357,30 @@ int gs_raster_tile_order(int32_t n_tiles, const int32_t* isect_offsets, int64_t 
                          int32_t* size_classes /* out, device int32[3] or NULL: #tiles with cost > 2048, > 1024, > 512;
                                                   the order is class-major, so these delimit contiguous ranges */,
                          void* stream);
+/* ... the same, and the kernel also stores the three size classes into size_classes_post[0..2] (NULL: not), part of a
+ * host slot from gs_host_post_alloc ("posted results" below). */
+int gs_raster_tile_order_post(int32_t n_tiles, const int32_t* isect_offsets, int64_t n_isects,
+                              const int32_t* tile_work, int32_t* tile_order, int32_t* size_classes,
+                              int32_t* size_classes_post, void* stream);
+
+/* ---- posted results (no reference counterpart: gsplat reads n_isects with a blocking device-to-host copy) ----------
+ * The pipeline's one host read -- n_isects, which sizes the arrays that follow -- costs more than the copy: a copy
+ * kernel behind the producer, the runtime's wake-up of the waiting thread, and a GPU that idles from then until the
+ * host has issued the next launches.  Here the producing kernels store their results straight into a host slot and the
+ * host polls it: the value is on the host a microsecond after the kernel computed it, while the launches queued behind
+ * the producer (tile order, flag clears) are still running.
+ *   gs_host_post_alloc   pinned, coherent (fine-grained) host memory mapped into the device's address space; keep it
+ *                        for the life of the process and give every host thread its own slot (>= 24 bytes: int64
+ *                        n_isects, then int32[3] size classes at byte offset 8)
+ *   gs_host_post_wait    spins until the slot(s) hold a posted value (sentinel -1, set by gs_isect_bin_prepare before it
+ *                        launches); after timeout_ms without one it synchronises `stream` and looks once more:
+ *                        GS_ERR_NOT_POSTED if still nothing, else GS_OK
+ * Only slots from gs_host_post_alloc may be given to the *_post entry points and to gs_isect_bin_prepare(synchronize = 2):
+ * other host memory may not be visible to the host before the stream is synchronised. */
+int gs_host_post_alloc(void** slot, int64_t bytes);
+int gs_host_post_free(void* slot);
+int gs_host_post_wait(const int64_t* n_isects_host, const int32_t* size_classes_host /* or NULL */,
+                      int32_t timeout_ms, void* stream);
 
 /* ---- composite launches (no reference counterpart: gsplat's Python layer issues its kernels one by one) ----------
  * Fixed launch sequences of the binned pipeline in one call each, for hosts whose per-call cost matters (the Python
@@ -362,6 +392,9 @@ int gs_raster_tile_order(int32_t n_tiles, const int32_t* isect_offsets, int64_t 
  *                            return *n_isects_host is valid (the pipeline's one host synchronisation; pinned memory
  *                            avoids a staging copy).  With synchronize == 0 the caller does its remaining host work
  *                            first and then calls gs_stream_synchronize(stream) before reading *n_isects_host.
+ *                            synchronize == 2 ("posted results" above): no copies are queued, the kernels post into
+ *                            n_isects_host / size_classes_host (slots from gs_host_post_alloc) and the caller waits
+ *                            with gs_host_post_wait.
  *   gs_isect_bin_build     = gs_isect_bin_scatter_regions (tile_counts = sorted_counts as it arrives: the list
  *                            lengths, or NULL) + gs_isect_tile_sort_front (k_target > 0; sorted_counts must then hold
  *                            the list lengths) or gs_isect_tile_sort (k_target == 0).

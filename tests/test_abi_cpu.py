@@ -199,6 +199,14 @@ def test_entry_points_reject_bad_arguments_before_any_launch():
     # composite launches: rejected before their first launch
     assert L.gs_isect_bin_prepare(1, 10, 4, 4, P, P, 1, P, P, P, None, 0, P, P, P, P, P, None, None, None, 1, None) == INVALID  # no host scalar
     assert L.gs_isect_bin_prepare(1, 10, too_many, 1, P, P, 1, P, P, P, None, 0, P, P, P, P, P, None, P, None, 1, None) == UNSUPPORTED
+    assert L.gs_isect_bin_prepare(1, 10, 4, 4, P, P, 1, P, P, P, None, 0, P, P, P, P, P, None, P, None, 3, None) == INVALID  # synchronize mode
+    # posted results: slots and waits
+    assert L.gs_host_post_alloc(None, 64) == INVALID
+    assert L.gs_host_post_wait(None, None, 10, None) == INVALID
+    assert L.gs_host_post_wait(P, None, -1, None) == INVALID
+    assert L.gs_isect_bin_offsets_post(0, 4, 4, 1, P, P, P, P, None, None) == INVALID
+    assert L.gs_raster_tile_order_post(10, None, 0, P, P, None, P, None) == INVALID  # posted classes without the device copy
+    assert b"post" in L.gs_error_string(-4).lower()
     assert L.gs_isect_bin_build(1, 10, 4, 4, 1, 0, 2, P, P, None, P, P, 5, P, P, 0, P, P, P, P, None, None) == INVALID  # slices_per_group < 1
     assert L.gs_rasterize_fwd_front(1, 64, 64, 16, 4, P, P, P, 5, None, 0, P, P, P, P, None, None, P, None, 10, None, P, P, P,
                                     None, None) == INVALID  # no sorted_counts

@@ -19,23 +19,31 @@ pytestmark = pytest.mark.gpu
     (3, 500, 78, 24, 0, 3),             # nothing longer than 1024: the short classes only
     (1, 9_000, 128, 128, 0, 1 << 20),   # 16384 tiles per camera: the largest LDS histogram the binned route takes
 ])
-def test_front_prefix_matches_full_order(gpu_device, C, N, TW, TH, hot, levels):
+@pytest.mark.parametrize("from_class", [0, 1])
+def test_front_prefix_matches_full_order(gpu_device, C, N, TW, TH, hot, levels, from_class):
+    import gsplat.cuda._wrapper as W
     from gsplat.cuda._wrapper import FRONT_K_TARGET, isect_tiles_binned
 
     rng = np.random.default_rng(7 + C * 1000 + N)
     rec, tiles, keys, ids, offsets = _synthetic_records(rng, C, N, TW, TH, hot, levels, gpu_device)
-    k, f, o, order, fs = isect_tiles_binned(rec, tiles, TW, TH, front=True)
+    saved = W.FRONT_FROM_CLASS
+    W.FRONT_FROM_CLASS = from_class  # the front-first sort is used from a list above 2048 (0) / 1024 (1) entries on
+    try:
+        k, f, o, order, fs = isect_tiles_binned(rec, tiles, TW, TH, front=True)
+    finally:
+        W.FRONT_FROM_CLASS = saved
     assert np.array_equal(o.cpu().numpy(), offsets)
     off = offsets.reshape(-1).astype(np.int64)
     end = np.append(off[1:], len(keys))
     n = end - off
+    limit = 2048 if from_class == 0 else 1024
     if fs is None:
-        # no list above 1024 entries: the host (which reads the size classes with n_isects) sorts every list whole and
-        # launches neither the front kernel nor the long classes
-        assert np.all(n <= 1024)
+        # no list above the limit: the host (which reads the size classes with n_isects) sorts every list whole and
+        # launches neither the front kernel nor the redo pass
+        assert np.all(n <= limit)
         assert np.array_equal(k.cpu().numpy(), keys) and np.array_equal(f.cpu().numpy(), ids)
         return
-    assert np.any(n > 1024)
+    assert np.any(n > limit)
     sc = fs.sorted_counts.cpu().numpy().astype(np.int64)
     assert np.all(sc >= 0) and np.all(sc <= n)
     assert np.all(sc[n <= 1024] == n[n <= 1024])          # short lists are sorted whole
@@ -59,7 +67,6 @@ def test_front_prefix_matches_full_order(gpu_device, C, N, TW, TH, hot, levels):
     fs.finalize()
     assert np.array_equal(k.cpu().numpy(), keys) and np.array_equal(f.cpu().numpy(), ids)
     # the slice scatter (no visible lists) fills the segments in another order; the sorted result is the same
-    import gsplat.cuda._wrapper as W
     W.REGION_SCATTER = False
     try:
         k2, f2, o2, _, _ = isect_tiles_binned(rec, tiles, TW, TH, front=False)
@@ -93,8 +100,9 @@ def test_front_sort_renders_identically(gpu_device, opac, expect_redo):
     wa = torch.randn(2, Hd, Wd, 1, generator=gen).to(dev)
 
     def run(front):
-        old = W.FRONT_SORT
+        old = (W.FRONT_SORT, W.FRONT_FROM_CLASS)
         W.FRONT_SORT = front
+        W.FRONT_FROM_CLASS = 1  # front-first from 1024 entries on (the culled lists of this scene stay under 2048)
         try:
             p = {k: v.to(dev).requires_grad_(True) for k, v in g.items()}
             rc, ra, meta = rasterization(p["means"], p["quats"], p["scales"], p["opacities"], p["colors"], vm.to(dev),
@@ -111,7 +119,7 @@ def test_front_sort_renders_identically(gpu_device, opac, expect_redo):
             grads["absgrad"] = meta["means2d"].absgrad.clone()
             return rc, ra, meta, grads, stats
         finally:
-            W.FRONT_SORT = old
+            W.FRONT_SORT, W.FRONT_FROM_CLASS = old
 
     rc1, ra1, m1, g1, st = run(True)
     rc0, ra0, m0, g0, st0 = run(False)
