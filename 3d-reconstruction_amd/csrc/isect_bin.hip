@@ -1125,6 +1125,9 @@ static inline int bin_ilog2_floor(int64_t v) {
 #ifndef GS_TS_G3
 #define GS_TS_G3 14
 #endif
+#ifndef GS_TS_W1  // waves per list of the 1025..2048 class (few lists, each a latency chain: see DESIGN.md section 6)
+#define GS_TS_W1 8
+#endif
 #ifndef GS_SCATTER_LDS  // LDS bytes of the staged region scatter (cursors + staging area), one workgroup per CU
 #define GS_SCATTER_LDS (163840 - 256)
 #endif
@@ -1298,7 +1301,7 @@ static int tile_sort_impl(int32_t C, int32_t tile_w, int32_t tile_h, const int32
     if (!ts_class_empty(sch, 0, n_tiles))
       hipLaunchKernelGGL((gs::tile_sort_kernel<6144, 0, 16>), dim3(256), dim3(1024), 0, s, GS_TS_ARGS);
     if (!ts_class_empty(sch, 1, n_tiles))
-      hipLaunchKernelGGL((gs::tile_sort_kernel<2048, 1, 4>), dim3(256 * 3), dim3(256), 0, s, GS_TS_ARGS);
+      hipLaunchKernelGGL((gs::tile_sort_kernel<2048, 1, GS_TS_W1>), dim3(256 * 3), dim3(64 * GS_TS_W1), 0, s, GS_TS_ARGS);
     if (!ts_class_empty(sch, 2, n_tiles))
       hipLaunchKernelGGL((gs::tile_sort_kernel<1024, 2, GS_TS_W2>), dim3(256 * GS_TS_G2), dim3(64 * GS_TS_W2), 0, s, GS_TS_ARGS);
     if (!ts_class_empty(sch, 3, n_tiles))
@@ -1359,7 +1362,7 @@ static int tile_sort_front_impl(int32_t C, int32_t tile_w, int32_t tile_h, const
       hipLaunchKernelGGL((gs::tile_sort_kernel<6144, 0, 16>), dim3(256), dim3(1024), 0, s, GS_TSF_ARGS,
                          (const int32_t*)sorted_counts, 0, sorted_counts);
     if (!ts_class_empty(sch, 1, n_tiles))
-      hipLaunchKernelGGL((gs::tile_sort_kernel<2048, 1, 4>), dim3(256 * 3), dim3(256), 0, s, GS_TSF_ARGS,
+      hipLaunchKernelGGL((gs::tile_sort_kernel<2048, 1, GS_TS_W1>), dim3(256 * 3), dim3(64 * GS_TS_W1), 0, s, GS_TSF_ARGS,
                          (const int32_t*)sorted_counts, 0, sorted_counts);
   }
   // short segments: sorted whole (sorted_counts was pre-filled with the list lengths by the caller)
@@ -1407,7 +1410,7 @@ static int tile_sort_redo_impl(int32_t C, int32_t tile_w, int32_t tile_h, const 
     hipLaunchKernelGGL((gs::tile_sort_kernel<6144, 0, 16>), dim3(256), dim3(1024), 0, s, GS_TSF_ARGS, redo_flags, 1,
                        sorted_counts);
   if (!ts_class_empty(sch, 1, n_tiles))
-    hipLaunchKernelGGL((gs::tile_sort_kernel<2048, 1, 4>), dim3(256 * 3), dim3(256), 0, s, GS_TSF_ARGS, redo_flags, 1,
+    hipLaunchKernelGGL((gs::tile_sort_kernel<2048, 1, GS_TS_W1>), dim3(256 * 3), dim3(64 * GS_TS_W1), 0, s, GS_TSF_ARGS, redo_flags, 1,
                        sorted_counts);
 #undef GS_TSF_ARGS
   GS_CHECK_LAUNCH();
