@@ -551,8 +551,6 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
     if fused:
         # one FFI call: count + offsets + tile order + the host read of n_isects (include/gsplat_mi355x.h, "composite
         # launches")
-        if use_front:
-            redo_flags = torch.empty(C * T + 1, device=dev, dtype=torch.int32)
         if POSTED_RESULTS:
             slot_addr, slot_n, slot_sc = _post_slot()
         else:
@@ -585,6 +583,8 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
             sc_host = (ctypes.c_int32 * 3)(*classes)
             if sc_host[FRONT_FROM_CLASS] == 0:
                 use_front = False
+        if use_front:  # (cleared here, once it is known that a front will be sorted, not by the prepare call)
+            redo_flags = torch.zeros(C * T + 1, device=dev, dtype=torch.int32)
     else:
         with B.device_guard(dev), B.timed("gs_isect_bin_count", dev):
             B.check(lib.gs_isect_bin_count(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
