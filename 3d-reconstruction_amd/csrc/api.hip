@@ -150,7 +150,7 @@ extern "C" int gs_rasterize_fwd_front(int32_t C, int32_t width, int32_t height, 
                                       int32_t* redo_flags, const float* opacity_override, int32_t n_per_camera,
                                       float* final_T, const int32_t* size_classes, uint64_t* pairs, int64_t* isect_ids,
                                       const int32_t* size_classes_host, void* stream) {
-  if (!sorted_counts || !redo_flags || !tile_order || !size_classes || !pairs || !isect_ids) return GS_ERR_INVALID_ARG;
+  if (!sorted_counts || !redo_flags || !tile_order || !size_classes || !pairs) return GS_ERR_INVALID_ARG;
   if (tile_size < 1) return GS_ERR_INVALID_ARG;
   int st = gs_rasterize_fwd(C, width, height, tile_size, channels, splats, isect_offsets, flatten_ids, n_isects,
                             backgrounds, ed_last_channel, render_colors, render_alphas, last_ids, tile_order, tile_work,

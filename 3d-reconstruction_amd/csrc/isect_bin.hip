@@ -946,10 +946,10 @@ __global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(int32_t T, int32_
       const uint2* cur = ts_sort<WAVES, uint16_t, true>(buf_a, buf_b, rank_s, n, sh);
       for (int i = threadIdx.x; i < n; i += THREADS) {
         const uint2 e = cur[i];
-        isect_ids[start + i] = key_hi | (int64_t)e.x;
+        if (isect_ids) isect_ids[start + i] = key_hi | (int64_t)e.x;
         flatten_ids[start + i] = (int32_t)e.y;
       }
-    } else if (CLS <= 0) {
+    } else if (CLS <= 0 && isect_ids) {  // (without the isect_ids array the host launches no class that needs scratch)
       // very long segment: same algorithm on global scratch -- the pair array, the (not yet written) isect_ids segment
       // as the second pair buffer, the flatten_ids segment as the rank array.  One workgroup owns the whole segment.
       uint2* ga = pairs + start;
@@ -1097,7 +1097,7 @@ __global__ __launch_bounds__(WAVES * 64) void tile_sort_front_kernel(
     const int64_t key_hi = (cam << (32 + tile_n_bits)) | (tl << 32);
     for (int i = tid; i < nf; i += THREADS) {
       const uint2 en = buf[i];
-      isect_ids[start + i] = key_hi | (int64_t)en.x;
+      if (isect_ids) isect_ids[start + i] = key_hi | (int64_t)en.x;
       flatten_ids[start + i] = (int32_t)en.y;
     }
     if (tid == 0) sorted_cnt[tile] = nf;
@@ -1280,14 +1280,23 @@ static inline bool ts_class_empty(const int32_t* sch, int cls, int64_t n_tiles) 
   return hi <= lo;
 }
 
+// isect_ids may be NULL (a caller that only rasterizes needs flatten_ids and the offsets) when no list is longer than
+// 2048 entries -- the longest class sorts on global scratch and borrows the isect_ids segment as its second buffer --
+// which the host can only know from its copy of the size classes.
+static inline bool ts_ids_optional(const int32_t* tile_order, const int32_t* size_classes, const int32_t* sch,
+                                   int64_t n_tiles) {
+  return tile_order && size_classes && sch && ts_class_empty(sch, 0, n_tiles);
+}
+
 static int tile_sort_impl(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets, int64_t n_isects,
                           const int32_t* tile_order, const int32_t* size_classes, uint64_t* pairs, int64_t* isect_ids,
                           int32_t* flatten_ids, const int32_t* sch, void* stream) {
   if (C < 1 || tile_w < 1 || tile_h < 1 || n_isects < 0) return GS_ERR_INVALID_ARG;
   if (n_isects == 0) return GS_OK;
   if (n_isects >= ((int64_t)1 << 31)) return GS_ERR_UNSUPPORTED;
-  if (!isect_offsets || !pairs || !isect_ids || !flatten_ids) return GS_ERR_INVALID_ARG;
+  if (!isect_offsets || !pairs || !flatten_ids) return GS_ERR_INVALID_ARG;
   const int T = tile_w * tile_h;
+  if (!isect_ids && !ts_ids_optional(tile_order, size_classes, sch, (int64_t)C * T)) return GS_ERR_INVALID_ARG;
   const int tile_n_bits = gs::bin_ilog2_floor(T) + 1;
   const int cam_n_bits = gs::bin_ilog2_floor(C) + 1;
   if (32 + tile_n_bits + cam_n_bits > 64) return GS_ERR_UNSUPPORTED;
@@ -1346,10 +1355,11 @@ static int tile_sort_front_impl(int32_t C, int32_t tile_w, int32_t tile_h, const
   int st = tile_sort_geom(C, tile_w, tile_h, n_isects, &T, &tile_n_bits);
   if (st != GS_OK) return st;
   if (n_isects == 0) return GS_OK;
-  if (!isect_offsets || !tile_order || !size_classes || !pairs || !isect_ids || !flatten_ids || !sorted_counts)
+  if (!isect_offsets || !tile_order || !size_classes || !pairs || !flatten_ids || !sorted_counts)
     return GS_ERR_INVALID_ARG;
   if (k_target < 1 || k_target > gs::TSF_MIN) return GS_ERR_INVALID_ARG;
   const int64_t n_tiles = (int64_t)C * T;
+  if (!isect_ids && !ts_ids_optional(tile_order, size_classes, sch, n_tiles)) return GS_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
   uint2* pr = reinterpret_cast<uint2*>(pairs);
 #define GS_TSF_ARGS T, tile_n_bits, n_tiles, isect_offsets, n_isects, tile_order, size_classes, pr, isect_ids, flatten_ids
@@ -1400,10 +1410,10 @@ static int tile_sort_redo_impl(int32_t C, int32_t tile_w, int32_t tile_h, const 
   int st = tile_sort_geom(C, tile_w, tile_h, n_isects, &T, &tile_n_bits);
   if (st != GS_OK) return st;
   if (n_isects == 0) return GS_OK;
-  if (!isect_offsets || !tile_order || !size_classes || !redo_flags || !pairs || !isect_ids || !flatten_ids ||
-      !sorted_counts)
+  if (!isect_offsets || !tile_order || !size_classes || !redo_flags || !pairs || !flatten_ids || !sorted_counts)
     return GS_ERR_INVALID_ARG;
   const int64_t n_tiles = (int64_t)C * T;
+  if (!isect_ids && !ts_ids_optional(tile_order, size_classes, sch, n_tiles)) return GS_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
   uint2* pr = reinterpret_cast<uint2*>(pairs);
   if (!ts_class_empty(sch, 0, n_tiles))

@@ -501,7 +501,7 @@ SIDE_STREAM_MIN_BYTES = 32 << 20
 
 
 def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int, tile_height: int,
-                       front: bool = False, cull_tile_size: int = 0, while_counting=None):
+                       front: bool = False, cull_tile_size: int = 0, while_counting=None, want_ids: bool = True):
     """isect_tiles + sort + isect_offset_encode in one binned pipeline (include/gsplat_mi355x.h, "binned isect_tiles").
     Returns (isect_ids int64 [I] sorted, flatten_ids int32 [I], isect_offsets int32 [C,TH,TW], tile_order, front_sort),
     the first three bit-identical to `isect_tiles_from_splats(sort=True)` + `isect_offset_encode`; tile_order is the
@@ -511,7 +511,9 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
     cull_tile_size > 0 (the rasterizer's tile edge in pixels): the culled lists of include/gsplat_mi355x.h -- a subset
     of gsplat's, each tile's list still in gsplat's order; the offsets describe the culled lists.
     while_counting: a callable run after the count / offsets launches are queued and before the host waits for
-    n_isects -- host work (allocations, independent launches) placed there hides behind the GPU's first stage."""
+    n_isects -- host work (allocations, independent launches) placed there hides behind the GPU's first stage.
+    want_ids=False: a caller that only rasterizes; isect_ids is then None unless a list is longer than 2048 entries
+    (the longest sort class borrows the array as scratch)."""
     dev = B.require_gpu(splats, tiles_per_gauss)
     assert not cull_tile_size or REGION_SCATTER, "culled lists need the region scatter"
     C, N = tiles_per_gauss.shape
@@ -604,7 +606,8 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
             sc_host = (ctypes.c_int32 * 3)(*n_long.tolist())
             if sc_host[FRONT_FROM_CLASS] == 0:
                 use_front = False
-    isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64)
+    need_ids = want_ids or use_front or sc_host is None or sc_host[0] > 0 or n_isects == 0
+    isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64) if need_ids else None
     flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
     if n_isects == 0:
         return isect_ids, flatten_ids, offsets, None, None
@@ -762,7 +765,8 @@ class _RasterizeSplats(torch.autograd.Function):
         if TW * TH <= bin_max_tiles():
             isect_ids, flatten_ids, offsets, order, fs = isect_tiles_binned(
                 splats, tiles_per_gauss, TW, TH, front=FRONT_SORT,
-                cull_tile_size=tile_size if (cull and REGION_SCATTER) else 0, while_counting=prepare_outputs)
+                cull_tile_size=tile_size if (cull and REGION_SCATTER) else 0, while_counting=prepare_outputs,
+                want_ids=not (cull and REGION_SCATTER))  # (culled lists are internal: meta builds gsplat's own on demand)
         else:
             order = None
             isect_ids, flatten_ids = isect_tiles_from_splats(splats, tiles_per_gauss, TW, TH)
@@ -833,6 +837,8 @@ class _RasterizeSplats(torch.autograd.Function):
         ctx.save_for_backward(splats, means2d, offsets, flatten_ids, bg if bg is not None else empty, rc, ra, last_ids,
                               packed_index if packed_index is not None else empty,
                               final_T if final_T is not None else empty)
+        if isect_ids is None:  # (culled internal lists without keys: an empty placeholder for the output slot)
+            isect_ids = torch.empty(0, device=dev, dtype=torch.int64)
         ctx.mark_non_differentiable(isect_ids, flatten_ids, offsets, last_ids)
         ctx.set_materialize_grads(False)  # no zero tensors for the integer outputs' (undefined) gradients
         return rc, ra, isect_ids, flatten_ids, offsets, last_ids

@@ -423,7 +423,10 @@ int gs_rasterize_fwd_front(int32_t C, int32_t width, int32_t height, int32_t til
 /* The three sort entry points with a HOST copy of size_classes (from gs_isect_bin_prepare; NULL = as the plain entry
  * points): launches for size classes that hold no tile are skipped -- on launch-bound shapes only the shortest class
  * exists, and a launch that finds nothing to do still costs microseconds.  gs_isect_tile_sort_front_ex with no tile
- * above 1024 entries launches neither the front kernel nor the long classes. */
+ * above 1024 entries launches neither the front kernel nor the long classes.
+ * With size_classes_host given and no list above 2048 entries (size_classes_host[0] == 0) isect_ids may be NULL: the
+ * keys are then not written (a third of the sort's output bytes) -- the rasterizer reads flatten_ids and the offsets
+ * only.  Longer lists are sorted on global scratch that borrows the isect_ids segment, so there it is required. */
 int gs_isect_tile_sort_ex(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets, int64_t n_isects,
                           const int32_t* tile_order, const int32_t* size_classes, uint64_t* pairs, int64_t* isect_ids,
                           int32_t* flatten_ids, const int32_t* size_classes_host, void* stream);

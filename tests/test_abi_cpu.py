@@ -200,6 +200,10 @@ def test_entry_points_reject_bad_arguments_before_any_launch():
     assert L.gs_isect_bin_prepare(1, 10, 4, 4, P, P, 1, P, P, P, None, 0, P, P, P, P, P, None, None, None, 1, None) == INVALID  # no host scalar
     assert L.gs_isect_bin_prepare(1, 10, too_many, 1, P, P, 1, P, P, P, None, 0, P, P, P, P, P, None, P, None, 1, None) == UNSUPPORTED
     assert L.gs_isect_bin_prepare(1, 10, 4, 4, P, P, 1, P, P, P, None, 0, P, P, P, P, P, None, P, None, 3, None) == INVALID  # synchronize mode
+    # the keys array is optional only when the host's size classes show that no list needs global scratch
+    assert L.gs_isect_tile_sort_ex(1, 4, 4, P, 5, P, P, P, None, P, None, None) == INVALID
+    three = (ctypes.c_int32 * 3)(1, 1, 1)
+    assert L.gs_isect_tile_sort_ex(1, 4, 4, P, 5, P, P, P, None, P, ctypes.addressof(three), None) == INVALID
     # posted results: slots and waits
     assert L.gs_host_post_alloc(None, 64) == INVALID
     assert L.gs_host_post_wait(None, None, 10, None) == INVALID
