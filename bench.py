@@ -30,6 +30,15 @@ for _p in (ROOT, os.path.join(ROOT, "3d-reconstruction_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+# Multi-rank runs use three streams per process (main, the side stream of the record fill / message-size negotiation, the
+# collectives' own): with HIP's default of 4 hardware queues per process, streams of PyTorch's pool land on shared queues
+# and the small cross-stream hand-overs of the gradient exchange serialise behind main-stream kernels (measured, forced
+# exchange on one rank: 1.29 -> 1.20 ms per step with 8 queues; the single-rank step does not change: 1.121 vs 1.122).
+# Set before anything initialises HIP; an explicit setting of 8 or more is kept.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--force-exchange" in sys.argv:
+    if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8:
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -206,6 +215,8 @@ def spawn_ranks(n: int) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+        if int(env.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8:
+            env["GPU_MAX_HW_QUEUES"] = "8"  # (see the top of this file)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     status = 0
     pending = set(range(n))
