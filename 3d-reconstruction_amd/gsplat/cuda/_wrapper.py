@@ -559,26 +559,33 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
             host_n = _host_scalar()
             slot_addr = host_n.data_ptr()
         with B.device_guard(dev):
-            B.check(lib.gs_isect_bin_prepare(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
-                                             n_slices, B.ptr(table), B.ptr(vis_list), B.ptr(vis_cnt), B.ptr(vis_masks),
-                                             int(cull_tile_size), B.ptr(counts), B.ptr(offsets), B.ptr(total),
-                                             B.ptr(order), B.ptr(n_long), B.ptr(redo_flags), slot_addr,
-                                             slot_addr + 8 if want_order else None, 2 if POSTED_RESULTS else 0, st),
-                    "gs_isect_bin_prepare")
-            if while_counting is not None:
-                while_counting()
-                while_counting = None
-            if POSTED_RESULTS:
-                # the kernels post n_isects / the size classes themselves: no copy kernels, no stream synchronisation,
-                # and the launches queued behind the producers (tile order, flag clears) still run while the host goes on
-                B.check(lib.gs_host_post_wait(slot_addr, slot_addr + 8 if want_order else None, 10_000, st),
-                        "gs_host_post_wait")
-                n_isects = int(slot_n[0])
-                classes = list(slot_sc) if want_order else None
-            else:
-                B.check(lib.gs_stream_synchronize(st), "gs_stream_synchronize")
-                n_isects = int(host_n[0])
-                classes = host_n.view(torch.int32)[2:5].tolist() if want_order else None
+            try:
+                B.check(lib.gs_isect_bin_prepare(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
+                                                 n_slices, B.ptr(table), B.ptr(vis_list), B.ptr(vis_cnt),
+                                                 B.ptr(vis_masks), int(cull_tile_size), B.ptr(counts), B.ptr(offsets),
+                                                 B.ptr(total), B.ptr(order), B.ptr(n_long), B.ptr(redo_flags), slot_addr,
+                                                 slot_addr + 8 if want_order else None, 2 if POSTED_RESULTS else 0, st),
+                        "gs_isect_bin_prepare")
+                if while_counting is not None:
+                    while_counting()
+                    while_counting = None
+                if POSTED_RESULTS:
+                    # the kernels post n_isects / the size classes themselves: no copy kernels, no stream
+                    # synchronisation, and the launches queued behind the producers (tile order) still run while the
+                    # host goes on
+                    B.check(lib.gs_host_post_wait(slot_addr, slot_addr + 8 if want_order else None, 10_000, st),
+                            "gs_host_post_wait")
+                    n_isects = int(slot_n[0])
+                    classes = list(slot_sc) if want_order else None
+                else:
+                    B.check(lib.gs_stream_synchronize(st), "gs_stream_synchronize")
+                    n_isects = int(host_n[0])
+                    classes = host_n.view(torch.int32)[2:5].tolist() if want_order else None
+            except BaseException:
+                # kernels that post into this thread's slot may still be in flight: let them finish, or their values
+                # would land in the slot after the NEXT call has armed it and be taken for that call's results
+                lib.gs_stream_synchronize(st)
+                raise
         if want_order:
             # host copy of the tile order's size classes: launches for classes that hold no tile are skipped, and
             # without a tile above 2048 entries there is no front to sort first
