@@ -55,8 +55,11 @@ extern "C" int gs_isect_bin_prepare(int32_t C, int32_t N, int32_t tile_w, int32_
       for (int i = 0; i < 3; ++i) __atomic_store_n(&size_classes_host[i], (int32_t)-1, __ATOMIC_RELAXED);
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
   }
+  // (posted: the offsets kernel also posts the size classes the tile order will find -- same counts, one kernel earlier)
+  const bool want_classes = tile_order && size_classes_host && size_classes;
   st = gs_isect_bin_offsets_post(C, tile_w, tile_h, n_slices, table, tile_counts, isect_offsets, total,
-                                 posted ? n_isects_host : nullptr, stream);
+                                 posted ? n_isects_host : nullptr,
+                                 (posted && want_classes) ? size_classes_host : nullptr, stream);
   if (st != GS_OK) return st;
   if (!posted) {
     // the one host synchronisation of the pipeline (gsplat has the same one): n_isects sizes the arrays that follow
@@ -64,9 +67,7 @@ extern "C" int gs_isect_bin_prepare(int32_t C, int32_t N, int32_t tile_w, int32_
     if (e != hipSuccess) return (int)e;
   }
   if (tile_order) {
-    const bool want_classes = size_classes_host && size_classes;
-    st = gs_raster_tile_order_post(n_tiles, nullptr, 0, tile_counts, tile_order, size_classes,
-                                   (posted && want_classes) ? size_classes_host : nullptr, stream);
+    st = gs_raster_tile_order(n_tiles, nullptr, 0, tile_counts, tile_order, size_classes, stream);
     if (st != GS_OK) return st;
     if (!posted && want_classes) {  // lets the host skip the launches of size classes that hold no tile
       e = hipMemcpyAsync(size_classes_host, size_classes, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s);

@@ -558,12 +558,15 @@ __global__ __launch_bounds__(256) void bin_slice_prefix_kernel(int32_t C, int32_
 // single workgroup: exclusive scan of the per-tile totals -> offsets, grand total -> *total
 __global__ __launch_bounds__(1024) void bin_offsets_kernel(int64_t n_tiles, const int32_t* __restrict__ counts,
                                                            int32_t* __restrict__ offsets, int64_t* __restrict__ total,
-                                                           int64_t* total_post) {
+                                                           int64_t* total_post, int32_t* classes_post) {
   __shared__ int64_t wsum[16];
   __shared__ int64_t carry_s;
+  __shared__ int32_t cls_s[3];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) carry_s = 0;
+  if (tid < 3) cls_s[tid] = 0;
   __syncthreads();
+  int32_t n_gt[3] = {0, 0, 0};  // this thread's lists longer than 2048 / 1024 / 512 entries (the sort's size classes)
   constexpr int ITEMS = 4;
   for (int64_t base = 0; base < n_tiles; base += 1024 * ITEMS) {
     const int64_t i0 = base + (int64_t)tid * ITEMS;
@@ -573,6 +576,9 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(int64_t n_tiles, cons
     for (int i = 0; i < ITEMS; ++i) {
       v[i] = (i0 + i < n_tiles) ? counts[i0 + i] : 0;
       s += v[i];
+      n_gt[0] += v[i] > TILE_LONG;
+      n_gt[1] += v[i] > 1024;
+      n_gt[2] += v[i] > 512;
     }
     int64_t incl = s;
 #pragma unroll
@@ -597,6 +603,19 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(int64_t n_tiles, cons
     __syncthreads();
     if (tid == 0) carry_s += all;
     __syncthreads();
+  }
+  if (classes_post) {
+    // the size classes gs_raster_tile_order will find (#lists > 2048, > 1024, > 512), posted from here: the host has
+    // them with n_isects, one kernel earlier than the tile order could give them
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      int32_t n = n_gt[c];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+      if (lane == 0 && n) atomicAdd(&cls_s[c], n);
+    }
+    __syncthreads();
+    if (tid < 3) __hip_atomic_store(&classes_post[tid], cls_s[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (tid == 0) {
     *total = carry_s;
@@ -1178,12 +1197,13 @@ extern "C" int gs_isect_bin_count(int32_t C, int32_t N, int32_t tile_w, int32_t 
 
 extern "C" int gs_isect_bin_offsets(int32_t C, int32_t tile_w, int32_t tile_h, int32_t n_slices, uint32_t* table,
                                     int32_t* tile_counts, int32_t* isect_offsets, int64_t* total, void* stream) {
-  return gs_isect_bin_offsets_post(C, tile_w, tile_h, n_slices, table, tile_counts, isect_offsets, total, nullptr, stream);
+  return gs_isect_bin_offsets_post(C, tile_w, tile_h, n_slices, table, tile_counts, isect_offsets, total, nullptr,
+                                   nullptr, stream);
 }
 
 extern "C" int gs_isect_bin_offsets_post(int32_t C, int32_t tile_w, int32_t tile_h, int32_t n_slices, uint32_t* table,
                                          int32_t* tile_counts, int32_t* isect_offsets, int64_t* total,
-                                         int64_t* total_post, void* stream) {
+                                         int64_t* total_post, int32_t* size_classes_post, void* stream) {
   if (C < 1 || tile_w < 1 || tile_h < 1 || n_slices < 1) return GS_ERR_INVALID_ARG;
   if (!table || !tile_counts || !isect_offsets || !total) return GS_ERR_INVALID_ARG;
   const int T = tile_w * tile_h;
@@ -1192,7 +1212,7 @@ extern "C" int gs_isect_bin_offsets_post(int32_t C, int32_t tile_w, int32_t tile
   hipLaunchKernelGGL(gs::bin_slice_prefix_kernel, dim3((unsigned)gs::ceil_div(n_tiles, 64)), dim3(256), 0, s, C, T,
                      n_slices, table, tile_counts);
   hipLaunchKernelGGL(gs::bin_offsets_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_counts, isect_offsets, total,
-                     total_post);
+                     total_post, size_classes_post);
   GS_CHECK_LAUNCH();
   return GS_OK;
 }

@@ -80,7 +80,7 @@ _SIGNATURES = {
     "gs_rasterize_fwd_front": (ctypes.c_int, [c_int32] * 5 + [_P, _P, _P, c_int64, _P, c_int32] + [_P] * 8 +
                                [c_int32, _P, _P, _P, _P, _P, _P]),
     "gs_isect_bin_offsets": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P]),
-    "gs_isect_bin_offsets_post": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
+    "gs_isect_bin_offsets_post": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "gs_isect_bin_scatter": (ctypes.c_int, [c_int32, c_int32, c_int32, c_int32, _P, _P, c_int32, _P, _P, _P, _P]),
     "gs_isect_bin_scatter_regions": (ctypes.c_int, [c_int32] * 7 + [_P] * 8),
     "gs_isect_tile_sort": (ctypes.c_int, [c_int32, c_int32, c_int32, _P, c_int64, _P, _P, _P, _P, _P, _P]),

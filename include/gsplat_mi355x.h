@@ -262,11 +262,13 @@ int gs_isect_bin_count(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, con
                        int32_t* vis_counts, uint64_t* vis_masks, int32_t tile_size, void* stream);
 int gs_isect_bin_offsets(int32_t C, int32_t tile_w, int32_t tile_h, int32_t n_slices, uint32_t* table,
                          int32_t* tile_counts, int32_t* isect_offsets, int64_t* total, void* stream);
-/* ... the same, and the kernel also stores the total into *total_post (NULL: not), a host slot from
- * gs_host_post_alloc that the caller polls with gs_host_post_wait ("posted results" below). */
+/* ... the same, and the kernel also stores the total into *total_post and the sort's size classes (#lists longer than
+ * 2048, 1024, 512 entries: what gs_raster_tile_order by list length will report) into size_classes_post[0..2] (either
+ * NULL: not), host slots from gs_host_post_alloc that the caller polls with gs_host_post_wait ("posted results"
+ * below). */
 int gs_isect_bin_offsets_post(int32_t C, int32_t tile_w, int32_t tile_h, int32_t n_slices, uint32_t* table,
                               int32_t* tile_counts, int32_t* isect_offsets, int64_t* total, int64_t* total_post,
-                              void* stream);
+                              int32_t* size_classes_post, void* stream);
 int gs_isect_bin_scatter(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, const float* splats,
                          const int32_t* tiles_per_gauss, int32_t n_slices, const uint32_t* table,
                          const int32_t* isect_offsets, uint64_t* pairs, void* stream);

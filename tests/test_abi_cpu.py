@@ -208,7 +208,7 @@ def test_entry_points_reject_bad_arguments_before_any_launch():
     assert L.gs_host_post_alloc(None, 64) == INVALID
     assert L.gs_host_post_wait(None, None, 10, None) == INVALID
     assert L.gs_host_post_wait(P, None, -1, None) == INVALID
-    assert L.gs_isect_bin_offsets_post(0, 4, 4, 1, P, P, P, P, None, None) == INVALID
+    assert L.gs_isect_bin_offsets_post(0, 4, 4, 1, P, P, P, P, None, None, None) == INVALID
     assert L.gs_raster_tile_order_post(10, None, 0, P, P, None, P, None) == INVALID  # posted classes without the device copy
     assert b"post" in L.gs_error_string(-4).lower()
     assert L.gs_isect_bin_build(1, 10, 4, 4, 1, 0, 2, P, P, None, P, P, 5, P, P, 0, P, P, P, P, None, None) == INVALID  # slices_per_group < 1

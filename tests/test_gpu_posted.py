@@ -25,8 +25,10 @@ def test_posted_and_copied_results_agree(gpu_device):
         for posted in (True, False, True):
             W.POSTED_RESULTS = posted
             k, f, o, order, fs = W.isect_tiles_binned(rec, tiles, TW, TH, front=True)
-            if fs is not None:
-                fs.finalize()
+            assert fs is not None  # (a list above 2048 entries: the front-first path, with the size classes in play)
+            if posted:  # the classes the offsets kernel posted are the ones the tile-order kernel found
+                assert list(W._post_slot()[2]) == fs.n_long.cpu().tolist()
+            fs.finalize()
             out[posted] = (k.cpu().numpy(), f.cpu().numpy(), o.cpu().numpy())
     finally:
         W.POSTED_RESULTS = saved
@@ -62,10 +64,12 @@ def test_wait_on_a_slot_nobody_posts_into_gives_up(gpu_device):
             offs = torch.empty(C * TW * TH, device=gpu_device, dtype=torch.int32)
             total = torch.empty(1, device=gpu_device, dtype=torch.int64)
             n[0] = -1
+            sc[0] = sc[1] = sc[2] = -1
             B.check(lib.gs_isect_bin_offsets_post(C, TW, TH, S, B.ptr(table), B.ptr(counts), B.ptr(offs), B.ptr(total),
-                                                  p.value, st), "gs_isect_bin_offsets_post")
-            assert lib.gs_host_post_wait(p.value, None, 10_000, st) == 0
+                                                  p.value, p.value + 8, st), "gs_isect_bin_offsets_post")
+            assert lib.gs_host_post_wait(p.value, p.value + 8, 10_000, st) == 0
             assert n[0] == S * TW * TH == int(total.item())
+            assert list(sc) == [0, 0, 0]  # no list above 512 entries
             assert torch.equal(offs.cpu(), torch.arange(TW * TH, dtype=torch.int32) * S)
         finally:
             torch.cuda.synchronize()
