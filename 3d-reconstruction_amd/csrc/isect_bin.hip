@@ -555,7 +555,10 @@ __global__ __launch_bounds__(256) void bin_slice_prefix_kernel(int32_t C, int32_
   }
 }
 
-// single workgroup: exclusive scan of the per-tile totals -> offsets, grand total -> *total
+// single workgroup: exclusive scan of the per-tile totals -> offsets, grand total -> *total.  ITEMS consecutive tiles per
+// thread and round; the host picks the smallest ITEMS that covers n_tiles in ONE round (each round is a chain of three
+// barriers on the path to the host's n_isects read)
+template <int ITEMS>
 __global__ __launch_bounds__(1024) void bin_offsets_kernel(int64_t n_tiles, const int32_t* __restrict__ counts,
                                                            int32_t* __restrict__ offsets, int64_t* __restrict__ total,
                                                            int64_t* total_post, int32_t* classes_post) {
@@ -567,7 +570,6 @@ __global__ __launch_bounds__(1024) void bin_offsets_kernel(int64_t n_tiles, cons
   if (tid < 3) cls_s[tid] = 0;
   __syncthreads();
   int32_t n_gt[3] = {0, 0, 0};  // this thread's lists longer than 2048 / 1024 / 512 entries (the sort's size classes)
-  constexpr int ITEMS = 4;
   for (int64_t base = 0; base < n_tiles; base += 1024 * ITEMS) {
     const int64_t i0 = base + (int64_t)tid * ITEMS;
     int32_t v[ITEMS];
@@ -1211,8 +1213,14 @@ extern "C" int gs_isect_bin_offsets_post(int32_t C, int32_t tile_w, int32_t tile
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(gs::bin_slice_prefix_kernel, dim3((unsigned)gs::ceil_div(n_tiles, 64)), dim3(256), 0, s, C, T,
                      n_slices, table, tile_counts);
-  hipLaunchKernelGGL(gs::bin_offsets_kernel, dim3(1), dim3(1024), 0, s, n_tiles, tile_counts, isect_offsets, total,
-                     total_post, size_classes_post);
+#define GS_BO_ARGS dim3(1), dim3(1024), 0, s, n_tiles, tile_counts, isect_offsets, total, total_post, size_classes_post
+  if (n_tiles <= 1024 * 4)
+    hipLaunchKernelGGL(gs::bin_offsets_kernel<4>, GS_BO_ARGS);
+  else if (n_tiles <= 1024 * 10)
+    hipLaunchKernelGGL(gs::bin_offsets_kernel<10>, GS_BO_ARGS);
+  else
+    hipLaunchKernelGGL(gs::bin_offsets_kernel<16>, GS_BO_ARGS);
+#undef GS_BO_ARGS
   GS_CHECK_LAUNCH();
   return GS_OK;
 }
