@@ -80,6 +80,19 @@ __device__ __forceinline__ void covar3d(const float Rq[9], const float s[3], flo
   S[5] = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
 }
 
+// a0 b0 + a1 b1 (+ a2 b2).  PIN: with the fusion spelled out -- the forward kernel exists in two instantiations that must
+// give one result (see projection_fwd_kernel); the backward, a single kernel, leaves it to the optimiser (0.002 ms).
+template <bool PIN>
+__device__ __forceinline__ float dot3(float a0, float b0, float a1, float b1, float a2, float b2) {
+  if constexpr (PIN) return fmaf(a2, b2, fmaf(a1, b1, a0 * b0));
+  return a0 * b0 + a1 * b1 + a2 * b2;
+}
+template <bool PIN>
+__device__ __forceinline__ float dot2(float a0, float b0, float a1, float b1) {
+  if constexpr (PIN) return fmaf(a1, b1, a0 * b0);
+  return a0 * b0 + a1 * b1;
+}
+
 __device__ __forceinline__ float sym(const float S[6], int i, int j) {
   // index into {00,01,02,11,12,22}
   constexpr int map[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
@@ -87,14 +100,15 @@ __device__ __forceinline__ float sym(const float S[6], int i, int j) {
 }
 
 // Cc = R S R^T (symmetric 6)
+template <bool PIN = false>
 __device__ __forceinline__ void covar_world_to_cam(const float R[9], const float S[6], float Cc[6]) {
   float A[9];  // A = R S
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j)
-      A[i * 3 + j] = R[i * 3 + 0] * sym(S, 0, j) + R[i * 3 + 1] * sym(S, 1, j) + R[i * 3 + 2] * sym(S, 2, j);
-  auto dot = [&](int i, int j) { return A[i * 3 + 0] * R[j * 3 + 0] + A[i * 3 + 1] * R[j * 3 + 1] + A[i * 3 + 2] * R[j * 3 + 2]; };
+      A[i * 3 + j] = dot3<PIN>(R[i * 3 + 0], sym(S, 0, j), R[i * 3 + 1], sym(S, 1, j), R[i * 3 + 2], sym(S, 2, j));
+  auto dot = [&](int i, int j) { return dot3<PIN>(A[i * 3 + 0], R[j * 3 + 0], A[i * 3 + 1], R[j * 3 + 1], A[i * 3 + 2], R[j * 3 + 2]); };
   Cc[0] = dot(0, 0); Cc[1] = dot(0, 1); Cc[2] = dot(0, 2);
   Cc[3] = dot(1, 1); Cc[4] = dot(1, 2); Cc[5] = dot(2, 2);
 }
@@ -109,6 +123,7 @@ struct Proj2D {
   bool in_x, in_y;          // clamp gates
 };
 
+template <bool PIN = false>
 __device__ __forceinline__ Proj2D persp_proj(const Cam& cam, const float mc[3], const float Cc[6], float W, float H,
                                              float eps2d) {
   Proj2D o;
@@ -128,27 +143,35 @@ __device__ __forceinline__ Proj2D persp_proj(const Cam& cam, const float mc[3], 
   o.Ja = cam.fx * rz; o.Jb = -cam.fx * o.tx * rz2;
   o.Jc = cam.fy * rz; o.Jd = -cam.fy * o.ty * rz2;
   // rows of J*Cc
-  const float v00 = o.Ja * Cc[0] + o.Jb * Cc[2];
-  const float v01 = o.Ja * Cc[1] + o.Jb * Cc[4];
-  const float v02 = o.Ja * Cc[2] + o.Jb * Cc[5];
-  const float v11 = o.Jc * Cc[3] + o.Jd * Cc[4];
-  const float v12 = o.Jc * Cc[4] + o.Jd * Cc[5];
-  const float c00 = v00 * o.Ja + v02 * o.Jb;
-  const float c01 = v01 * o.Jc + v02 * o.Jd;
-  const float c11 = v11 * o.Jc + v12 * o.Jd;
-  o.mx = cam.fx * x * rz + cam.cx;
-  o.my = cam.fy * y * rz + cam.cy;
-  const float det_orig = c00 * c11 - c01 * c01;
+  const float v00 = dot2<PIN>(o.Ja, Cc[0], o.Jb, Cc[2]);
+  const float v01 = dot2<PIN>(o.Ja, Cc[1], o.Jb, Cc[4]);
+  const float v02 = dot2<PIN>(o.Ja, Cc[2], o.Jb, Cc[5]);
+  const float v11 = dot2<PIN>(o.Jc, Cc[3], o.Jd, Cc[4]);
+  const float v12 = dot2<PIN>(o.Jc, Cc[4], o.Jd, Cc[5]);
+  const float c00 = dot2<PIN>(v00, o.Ja, v02, o.Jb);
+  const float c01 = dot2<PIN>(v01, o.Jc, v02, o.Jd);
+  const float c11 = dot2<PIN>(v11, o.Jc, v12, o.Jd);
+  o.mx = PIN ? fmaf(cam.fx * x, rz, cam.cx) : cam.fx * x * rz + cam.cx;
+  o.my = PIN ? fmaf(cam.fy * y, rz, cam.cy) : cam.fy * y * rz + cam.cy;
+  const float det_orig = PIN ? fmaf(c00, c11, -(c01 * c01)) : c00 * c11 - c01 * c01;
   o.c00 = c00 + eps2d;
   o.c11 = c11 + eps2d;
   o.c01 = c01;
-  o.det = o.c00 * o.c11 - c01 * c01;
+  o.det = PIN ? fmaf(o.c00, o.c11, -(c01 * c01)) : o.c00 * o.c11 - c01 * c01;
   o.comp = sqrtf(fmaxf(0.f, det_orig / o.det));
   return o;
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <int CMODE, int DEG>
+// PREFETCH (SH colours): the Gaussian's coefficient row is requested up front, behind the geometry loads, whether or not a
+// camera will see it -- right when most Gaussians are seen by some camera (5-camera rig: 87 %).  !PREFETCH: the row is
+// requested at the first camera that sees the Gaussian; with one or two cameras, or a few neighbouring views of a
+// trajectory, three quarters of the rows are never needed (1 M Gaussians, one camera: 0.086 -> 0.048 ms; 6 M x 3
+// trajectory views: 2177 -> 2416 views/s; five rig cameras: 0.111 -> 0.127 ms, which is why the host chooses).
+// Two instantiations must give a camera the same bits whether it is projected alone or in a batch of five: the geometry
+// helpers above therefore spell their multiply-adds out (fmaf) instead of leaving the fusion of a*b + c*d + e*f to the
+// optimiser, which resolved it differently in the two kernels.
+template <int CMODE, int DEG, bool PREFETCH = true>
 __global__ __launch_bounds__(256, (CMODE == GS_COLOR_SH && DEG == 4) ? 1 : 4) void projection_fwd_kernel(
     gs_proj_params p, const float* __restrict__ means, const float* __restrict__ quats,
     const float* __restrict__ scales, const float* __restrict__ opacities, const float* __restrict__ viewmats,
@@ -178,10 +201,11 @@ __global__ __launch_bounds__(256, (CMODE == GS_COLOR_SH && DEG == 4) ? 1 : 4) vo
   // per-camera branch where every visible camera would wait for them again
   constexpr int NB3 = (CMODE == GS_COLOR_SH) ? 3 * (DEG + 1) * (DEG + 1) : 1;
   float creg[NB3];
-#ifndef GS_EXP_NOPREFETCH
-  if constexpr (CMODE == GS_COLOR_SH)
+  bool have_row = false;
+  if constexpr (CMODE == GS_COLOR_SH && PREFETCH) {
     sh_load_row<NB3>(colors + (int64_t)n * p.sh_K * 3, (p.sh_K % 4 == 0) && aligned16(colors), creg);
-#endif
+    have_row = true;
+  }
   const float opac = opacities[n];
   float S[6];
   if (covars) {  // precomputed world covariances (gsplat `covars=`), upper triangle {xx,xy,xz,yy,yz,zz}
@@ -210,14 +234,14 @@ __global__ __launch_bounds__(256, (CMODE == GS_COLOR_SH && DEG == 4) ? 1 : 4) vo
     const Cam cam = load_cam(viewmats, Ks, c);
     float mc[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) mc[i] = cam.R[i * 3] * mu[0] + cam.R[i * 3 + 1] * mu[1] + cam.R[i * 3 + 2] * mu[2] + cam.t[i];
+    for (int i = 0; i < 3; ++i) mc[i] = fmaf(cam.R[i * 3 + 2], mu[2], fmaf(cam.R[i * 3 + 1], mu[1], fmaf(cam.R[i * 3], mu[0], cam.t[i])));
     bool ok = live && (mc[2] >= p.near_plane) && (mc[2] <= p.far_plane);
     Proj2D pr;
     float radius = 0.f;
     if (ok) {
       float Cc[6];
-      covar_world_to_cam(cam.R, S, Cc);
-      pr = persp_proj(cam, mc, Cc, W, H, p.eps2d);
+      covar_world_to_cam<true>(cam.R, S, Cc);
+      pr = persp_proj<true>(cam, mc, Cc, W, H, p.eps2d);
       ok = pr.det > 0.f;
       if (ok) {
         const float b = 0.5f * (pr.c00 + pr.c11);
@@ -268,9 +292,12 @@ __global__ __launch_bounds__(256, (CMODE == GS_COLOR_SH && DEG == 4) ? 1 : 4) vo
       float rgb[3];
       float cp[3];
       cam_center(campos, cam, c, cp);
-#ifdef GS_EXP_NOPREFETCH
-      sh_load_row<NB3>(colors + (int64_t)n * p.sh_K * 3, (p.sh_K % 4 == 0) && aligned16(colors), creg);
-#endif
+      if constexpr (!PREFETCH) {
+        if (!have_row) {
+          sh_load_row<NB3>(colors + (int64_t)n * p.sh_K * 3, (p.sh_K % 4 == 0) && aligned16(colors), creg);
+          have_row = true;
+        }
+      }
       sh_eval<DEG>(creg, mu[0] - cp[0], mu[1] - cp[1], mu[2] - cp[2], rgb);
 #pragma unroll
       for (int k = 0; k < 3; ++k) ch[k] = fmaxf(rgb[k] + 0.5f, 0.f);
@@ -699,6 +726,13 @@ static int check_params(const gs_proj_params* p) {
 
 #define GS_FWD_ARGS *p, means, quats, scales, opacities, viewmats, Ks, campos, colors, radii, means2d, splats, tiles_per_gauss, covars, vis_words, vis_counts
 #define GS_FWD_LAUNCH(CM, DG) hipLaunchKernelGGL((gs::projection_fwd_kernel<CM, DG>), grid, block, 0, s, GS_FWD_ARGS)
+#define GS_FWD_LAUNCH_SH(DG)                                                                                  \
+  do {                                                                                                        \
+    if (prefetch_rows)                                                                                        \
+      hipLaunchKernelGGL((gs::projection_fwd_kernel<GS_COLOR_SH, DG, true>), grid, block, 0, s, GS_FWD_ARGS); \
+    else                                                                                                      \
+      hipLaunchKernelGGL((gs::projection_fwd_kernel<GS_COLOR_SH, DG, false>), grid, block, 0, s, GS_FWD_ARGS); \
+  } while (0)
 
 extern "C" int gs_projection_fwd(const gs_proj_params* p, const float* means, const float* quats,
                                  const float* scales, const float* opacities, const float* viewmats,
@@ -715,17 +749,21 @@ extern "C" int gs_projection_fwd(const gs_proj_params* p, const float* means, co
   if (p->color_mode != GS_COLOR_NONE && !colors) return GS_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)gs::ceil_div(p->N, 256)), block(256);
+  // coefficient rows up front only when most of them will be used: from four cameras on (measured crossover on the
+  // 5-camera rig at 1 M Gaussians: 1 camera 0.086 / 0.048 ms prefetched / on demand, 2: 0.090 / 0.076, 3: 0.095 / 0.101,
+  // 4: 0.104 / 0.121, 5: 0.111 / 0.127; three neighbouring trajectory views see almost the same Gaussians: on demand)
+  const bool prefetch_rows = p->C >= 4;
   switch (p->color_mode) {
     case GS_COLOR_NONE: GS_FWD_LAUNCH(GS_COLOR_NONE, 0); break;
     case GS_COLOR_N: GS_FWD_LAUNCH(GS_COLOR_N, 0); break;
     case GS_COLOR_CN: GS_FWD_LAUNCH(GS_COLOR_CN, 0); break;
     default:
       switch (p->sh_degree) {
-        case 0: GS_FWD_LAUNCH(GS_COLOR_SH, 0); break;
-        case 1: GS_FWD_LAUNCH(GS_COLOR_SH, 1); break;
-        case 2: GS_FWD_LAUNCH(GS_COLOR_SH, 2); break;
-        case 3: GS_FWD_LAUNCH(GS_COLOR_SH, 3); break;
-        default: GS_FWD_LAUNCH(GS_COLOR_SH, 4); break;
+        case 0: GS_FWD_LAUNCH_SH(0); break;
+        case 1: GS_FWD_LAUNCH_SH(1); break;
+        case 2: GS_FWD_LAUNCH_SH(2); break;
+        case 3: GS_FWD_LAUNCH_SH(3); break;
+        default: GS_FWD_LAUNCH_SH(4); break;
       }
   }
   GS_CHECK_LAUNCH();

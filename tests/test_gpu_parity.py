@@ -242,6 +242,33 @@ def test_projection_fwd(gpu_device):
     assert_close("opacities*comp", meta["opacities"].cpu()[both], mo["opacities"][both])
 
 
+def test_projection_is_bitwise_the_same_alone_and_in_a_batch(gpu_device):
+    """gs_projection_fwd runs one of two kernels (SH coefficient rows requested up front from four cameras on, on demand
+    below): a camera's splat records must not depend on which one projected it."""
+    from gsplat import _backend as B
+    from gsplat.cuda import _wrapper as Wm
+
+    N, C, W, H = 30_000, 5, 310, 94
+    g = to_dev(synth_scene.make_gaussians(N, sh_degree=3, seed=4, extent=15.0), gpu_device)
+    vm, Ks = (t.to(gpu_device) for t in synth_scene.make_cameras(C, W, H, frame=2))
+
+    def project(vm, Ks):
+        params = Wm._make_params(N, vm.shape[0], W, H, 16, 0.3, 0.1, 1e10, 0.0, True, B.GS_COLOR_SH, 3, 3, 16, True)
+        with torch.no_grad():
+            return Wm._ProjectSplats.apply(g["means"], g["quats"], g["scales"], g["opacities"], g["colors"], vm, Ks,
+                                           None, params, None)
+
+    sp5, _, r5, t5 = project(vm, Ks)
+    seen = 0
+    for c in range(C):
+        sp1, _, r1, t1 = project(vm[c:c + 1], Ks[c:c + 1])
+        assert torch.equal(r5[c], r1[0]) and torch.equal(t5[c], t1[0])
+        vis = t5[c] > 0
+        seen += int(vis.sum())
+        assert torch.equal(sp5[c][vis], sp1[0][vis]), f"camera {c}: records differ between the batch and the single call"
+    assert seen > 1000
+
+
 def test_isect_sort_offsets_bit_exact(gpu_device):
     """Integer stages are compared bit-for-bit: the oracle is fed the GPU's own fp32 means2d/radii/depths."""
     for (W, H, C, N) in [(160, 96, 2, 4096), (375, 250, 5, 20000), (33, 17, 1, 300)]:
