@@ -29,6 +29,38 @@ extern "C" int gs_fill_zero(void* ptr, int64_t bytes, void* stream) {
   return e == hipSuccess ? GS_OK : (int)e;
 }
 
+// ------------------------------------------------------------------------------------------ frames -> uint8
+// The reference's host-side frame conversion (models/video_utils.py:694-700: rgb.clip(1e-6, 1 - 1e-6), (rgb * 255)
+// .astype(np.uint8): truncation) in one pass over the rendered floats instead of three elementwise kernels.
+namespace gs {
+__device__ __forceinline__ unsigned frame_u8(float x) {
+  const float lo = 1.0e-6f, hi = (float)(1.0 - 1.0e-6);
+  const float v = fminf(fmaxf(x, lo), hi) * 255.0f;
+  return (unsigned)(int)v;
+}
+__global__ __launch_bounds__(256) void frames_to_uint8_kernel(int64_t n, const float* __restrict__ src,
+                                                              unsigned char* __restrict__ dst) {
+  const int64_t i4 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 + 4 <= n && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+    const float4 v = *reinterpret_cast<const float4*>(src + i4);
+    *reinterpret_cast<unsigned*>(dst + i4) =
+        frame_u8(v.x) | (frame_u8(v.y) << 8) | (frame_u8(v.z) << 16) | (frame_u8(v.w) << 24);
+  } else {
+    for (int64_t i = i4; i < n && i < i4 + 4; ++i) dst[i] = (unsigned char)frame_u8(src[i]);
+  }
+}
+}  // namespace gs
+
+extern "C" int gs_frames_to_uint8(int64_t n, const float* src, uint8_t* dst, void* stream) {
+  if (n < 0 || (n > 0 && (!src || !dst))) return GS_ERR_INVALID_ARG;
+  if (n == 0) return GS_OK;
+  const int64_t blocks = gs::ceil_div(gs::ceil_div(n, (int64_t)4), (int64_t)256);
+  if (blocks > 0x7fffffff) return GS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gs::frames_to_uint8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, src, dst);
+  GS_CHECK_LAUNCH();
+  return GS_OK;
+}
+
 // ------------------------------------------------------------------------------------------ composite launches
 // The host side of one rasterization() call is a dozen launches; on the shapes the reference trains at (one camera,
 // 1e5 Gaussians) the step is bound by the host reaching them, not by the kernels.  These entry points issue the fixed

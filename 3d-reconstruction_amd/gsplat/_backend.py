@@ -50,6 +50,7 @@ _SIGNATURES = {
     "gs_version": (ctypes.c_int, []),
     "gs_error_string": (c_char_p, [ctypes.c_int]),
     "gs_fill_zero": (ctypes.c_int, [_P, c_int64, _P]),
+    "gs_frames_to_uint8": (ctypes.c_int, [c_int64, _P, _P, _P]),
     "gs_projection_fwd": (ctypes.c_int, [POINTER(ProjParams)] + [_P] * 15 + [_P]),
     "gs_colour_message_layout": (ctypes.c_int, [c_int32, c_int32, c_int64, POINTER(c_int64)]),
     "gs_projection_bwd_split": (ctypes.c_int, [POINTER(ProjParams)] + [_P] * 10 + [c_int64] + [_P] * 8 + [c_int64, c_int32, _P]),

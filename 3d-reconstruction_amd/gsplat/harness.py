@@ -21,8 +21,15 @@ from .rendering import no_eval_cache, rasterization
 
 
 def frames_to_uint8(rgb: Tensor) -> Tensor:
-    """video_utils.py:694-700: `rgb.clip(min=1e-6, max=1 - 1e-6)`, `(rgb * 255).astype(np.uint8)` (truncation)."""
-    return (rgb.clamp(1.0e-6, 1.0 - 1.0e-6) * 255.0).to(torch.uint8)
+    """video_utils.py:694-700: `rgb.clip(min=1e-6, max=1 - 1e-6)`, `(rgb * 255).astype(np.uint8)` (truncation), in one
+    pass on the device (gs_frames_to_uint8)."""
+    dev = B.require_gpu(rgb)
+    src = B.f32c(rgb)
+    out = torch.empty(src.shape, device=dev, dtype=torch.uint8)
+    with B.device_guard(dev):
+        B.check(B.lib().gs_frames_to_uint8(src.numel(), B.ptr(src), B.ptr(out), B.stream_handle(dev)),
+                "gs_frames_to_uint8")
+    return out
 
 
 def render_trajectory(means: Tensor, quats: Tensor, scales: Tensor, opacities: Tensor, colors: Tensor,

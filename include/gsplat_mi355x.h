@@ -76,6 +76,10 @@ int gs_version(void);
 const char* gs_error_string(int status);
 /* hipMemsetAsync(ptr, 0, bytes) on `stream`: clears the gradient record gs_rasterize_bwd accumulates into. */
 int gs_fill_zero(void* ptr, int64_t bytes, void* stream);
+/* Rendered floats -> video frames as the reference converts them on the host
+ * (/root/reference/3D-Reconstruction-main/models/video_utils.py:694-700): dst[i] = (uint8)(clip(src[i], 1e-6, 1 - 1e-6) * 255),
+ * truncated; one pass.  n = number of values. */
+int gs_frames_to_uint8(int64_t n, const float* src, uint8_t* dst, void* stream);
 
 /* ---- fully_fused_projection (+SH, +opacity*comp, +tile count) ------------------------------- */
 int gs_projection_fwd(const gs_proj_params* p,

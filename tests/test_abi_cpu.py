@@ -204,6 +204,9 @@ def test_entry_points_reject_bad_arguments_before_any_launch():
     assert L.gs_isect_tile_sort_ex(1, 4, 4, P, 5, P, P, P, None, P, None, None) == INVALID
     three = (ctypes.c_int32 * 3)(1, 1, 1)
     assert L.gs_isect_tile_sort_ex(1, 4, 4, P, 5, P, P, P, None, P, ctypes.addressof(three), None) == INVALID
+    assert L.gs_frames_to_uint8(-1, P, P, None) == INVALID
+    assert L.gs_frames_to_uint8(8, None, P, None) == INVALID
+    assert L.gs_frames_to_uint8(0, None, None, None) == 0
     # posted results: slots and waits
     assert L.gs_host_post_alloc(None, 64) == INVALID
     assert L.gs_host_post_wait(None, None, 10, None) == INVALID

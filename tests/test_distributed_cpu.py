@@ -12,6 +12,18 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _by_value(d):
+    """Tensors leave the worker as numpy arrays: pickled by value.  A tensor is passed as a file descriptor that the
+    parent fetches from the worker when it unpickles -- too late if the worker has exited by then."""
+    return {k: (v.detach().numpy() if torch.is_tensor(v) else v) for k, v in d.items()}
+
+
+def _tensors(d):
+    import numpy as np
+
+    return {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in d.items()}
+
+
 def _worker(rank, world, port, q):
     for p in (ROOT, os.path.join(ROOT, "3d-reconstruction_amd")):
         if p not in sys.path:
@@ -44,7 +56,7 @@ def _worker(rank, world, port, q):
     rmax = meta["radii"].max(0).values.double()
     all_reduce_densification_stats(gsum, vis, rmax)
     if rank == 0:
-        q.put({k: v.grad.clone() for k, v in params.items()} | {"vis": vis, "gsum": gsum, "rmax": rmax})
+        q.put(_by_value({k: v.grad.clone() for k, v in params.items()} | {"vis": vis, "gsum": gsum, "rmax": rmax}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -61,7 +73,7 @@ def test_two_rank_camera_sharding_matches_single_process():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=300)
+    got = _tensors(q.get(timeout=300))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -145,7 +157,7 @@ def _colour_worker(rank, world, port, q):
     all_reduce_gradients((t for t in probe), average=True)
     out["avg"] = probe[1].grad.clone()
     if rank == 0:
-        q.put(out)
+        q.put(_by_value(out))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -164,7 +176,7 @@ def test_colour_exchange_two_ranks_matches_single_process():
     procs = [ctx.Process(target=_colour_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=300)
+    got = _tensors(q.get(timeout=300))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

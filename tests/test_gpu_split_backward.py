@@ -129,7 +129,9 @@ def _rank_main(rank, world, port, mode, q):
                                      render_mode="RGB+ED", absgrad=True, rasterize_mode="antialiased")
     ((rc * wc).sum() + (ra * wa).sum()).backward()
     torch.cuda.synchronize()
-    q.put((rank, {k: v.grad.cpu() for k, v in p.items()}, ex.bytes_sent))
+    # (numpy arrays are pickled by value; a tensor would be fetched from this process when the parent unpickles it,
+    # which fails if this process has exited by then)
+    q.put((rank, {k: v.grad.cpu().numpy() for k, v in p.items()}, ex.bytes_sent))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -148,7 +150,7 @@ def test_two_ranks_equal_single_process(gpu_device, mode):
     got = {}
     for _ in range(world):
         r, grads, sent = q.get(timeout=300)
-        got[r] = (grads, sent)
+        got[r] = ({k: torch.from_numpy(v) for k, v in grads.items()}, sent)
     for p_ in procs:
         p_.join(timeout=120)
         assert p_.exitcode == 0
@@ -209,7 +211,7 @@ def _rccl_main(port, mode, q):
     t = torch.tensor([1.5], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)  # bench.py's max-over-ranks timing
     torch.cuda.synchronize()
-    q.put(({k: v.cpu() for k, v in grads.items()}, ex.bytes_sent, float(t.item())))
+    q.put(({k: v.cpu().numpy() for k, v in grads.items()}, ex.bytes_sent, float(t.item())))
     dist.destroy_process_group()
 
 
@@ -225,6 +227,7 @@ def test_exchange_over_a_one_rank_rccl_group(gpu_device, mode):
     proc = ctx.Process(target=_rccl_main, args=(port, mode, q))
     proc.start()
     grads, sent, tmax = q.get(timeout=300)
+    grads = {k: torch.from_numpy(v) for k, v in grads.items()}
     proc.join(timeout=120)
     assert proc.exitcode == 0
     assert tmax == 1.5 and sent > 0
