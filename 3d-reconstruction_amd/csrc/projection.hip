@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, (CMODE == GS_COLOR_SH && DEG == 4) ? 1 : 4) vo
       if (live) {
         radii[idx] = 0;
         tiles_per_gauss[idx] = 0;
-        reinterpret_cast<float2*>(means2d)[idx] = make_float2(0.f, 0.f);
+        if (means2d) reinterpret_cast<float2*>(means2d)[idx] = make_float2(0.f, 0.f);
       }
       continue;
     }
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256, (CMODE == GS_COLOR_SH && DEG == 4) ? 1 : 4) vo
 
     radii[idx] = (int32_t)radius;
     tiles_per_gauss[idx] = (y1 - y0) * (x1 - x0);
-    reinterpret_cast<float2*>(means2d)[idx] = make_float2(pr.mx, pr.my);
+    if (means2d) reinterpret_cast<float2*>(means2d)[idx] = make_float2(pr.mx, pr.my);
     float4* rec = reinterpret_cast<float4*>(splats + idx * REC);
     rec[0] = make_float4(pr.mx, pr.my, pr.c11 * idet, -pr.c01 * idet);
     rec[1] = make_float4(pr.c00 * idet, opac * comp, ch[0], ch[1]);
@@ -743,8 +743,7 @@ extern "C" int gs_projection_fwd(const gs_proj_params* p, const float* means, co
   if (st != GS_OK) return st;
   if (p->N == 0) return GS_OK;
   if ((vis_words == nullptr) != (vis_counts == nullptr)) return GS_ERR_INVALID_ARG;
-  if (!means || !opacities || !viewmats || !Ks || !radii || !means2d || !splats || !tiles_per_gauss)
-    return GS_ERR_INVALID_ARG;
+  if (!means || !opacities || !viewmats || !Ks || !radii || !splats || !tiles_per_gauss) return GS_ERR_INVALID_ARG;
   if (!covars && (!quats || !scales)) return GS_ERR_INVALID_ARG;
   if (p->color_mode != GS_COLOR_NONE && !colors) return GS_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;

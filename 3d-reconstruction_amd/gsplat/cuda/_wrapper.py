@@ -143,7 +143,11 @@ class _ProjectSplats(torch.autograd.Function):
         campos = B.f32c(campos) if campos is not None else None
         radii = torch.empty(C, N, device=dev, dtype=torch.int32)
         tiles = torch.empty(C, N, device=dev, dtype=torch.int32)
-        means2d = torch.empty(C, N, 2, device=dev, dtype=torch.float32)
+        # the dense [C,N,2] means2d is what gradients hang on and what a dense `meta` shows; a caller that wants neither
+        # (packed, no gradients: the render-only harness) sets _tls.skip_means2d and the 8 bytes per (camera, Gaussian)
+        # are not written (the records hold the means of the visible rows)
+        skip_m2d = getattr(_tls, "skip_means2d", False) and not torch.is_grad_enabled()
+        means2d = None if skip_m2d else torch.empty(C, N, 2, device=dev, dtype=torch.float32)
         # rows with radii == 0 are never written nor read (as gsplat's torch.empty projection outputs)
         splats = torch.empty(C, N, B.GS_REC, device=dev, dtype=torch.float32)
         # split SH backward: the forward also leaves each camera's visibility words; their scanned populations give

@@ -257,8 +257,12 @@ def rasterization(
 
     params = W._make_params(N, C, width, height, tile_size, eps2d, near_plane, far_plane, radius_clip,
                             rasterize_mode == "antialiased", color_mode, color_dim, sh_degree, sh_K, want_depth)
-    splats, means2d, radii, tiles_per_gauss = W._ProjectSplats.apply(
-        means, quats, scales, opacities, col_in, viewmats, Ks, campos, params, covars)
+    W._tls.skip_means2d = bool(packed and not needs_grad)  # (packed `meta` takes the means from the records, on demand)
+    try:
+        splats, means2d, radii, tiles_per_gauss = W._ProjectSplats.apply(
+            means, quats, scales, opacities, col_in, viewmats, Ks, campos, params, covars)
+    finally:
+        W._tls.skip_means2d = False
 
     TW, TH = math.ceil(width / tile_size), math.ceil(height / tile_size)
     meta: Dict = _Meta()
@@ -270,8 +274,9 @@ def rasterization(
         # The rasterizer itself always works on the dense [C,N] records; the CSR arrays are a compaction of them.
         def pack(_memo={}):
             if not _memo:
+                m2d = means2d if means2d is not None else splats.detach()[..., 0:2].contiguous()
                 camera_ids, gaussian_ids, radii_p, means2d_p, depths_p, conics_p, packed_index, cum = _pack_meta(
-                    splats, means2d, radii)
+                    splats, m2d, radii)
                 _memo.update({"camera_ids": camera_ids, "gaussian_ids": gaussian_ids, "radii": radii_p,
                               "means2d": means2d_p, "depths": depths_p, "conics": conics_p, "_index": packed_index,
                               "_cum": cum,

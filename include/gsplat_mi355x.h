@@ -92,7 +92,7 @@ int gs_projection_fwd(const gs_proj_params* p,
                       const float* campos,     /* [C,3] camera centres for the SH view directions; NULL: derived from viewmats in-kernel */
                       const float* colors,     /* per color_mode, may be NULL   */
                       int32_t* radii,          /* out [C,N]                     */
-                      float* means2d,          /* out [C,N,2]                   */
+                      float* means2d,          /* out [C,N,2], or NULL: not written  */
                       float* splats,           /* out [C,N,16], rows with radii==0 untouched */
                       int32_t* tiles_per_gauss,/* out [C,N]                     */
                       const float* covars,     /* [N,6] world covariances {xx,xy,xz,yy,yz,zz} (gsplat `covars=`) or NULL;

@@ -473,3 +473,12 @@ def test_packed_meta(gpu_device):
     assert torch.equal(mb["means2d"], ma["means2d"][vis])
     assert torch.equal(mb["depths"], ma["depths"][vis])
     assert torch.equal(mb["conics"], ma["conics"][vis])
+    # packed under no_grad (the render-only harness): the dense means2d is not written at all, `meta` takes the means of
+    # the visible rows from the splat records
+    with torch.no_grad():
+        c = rasterization(gg["means"], gg["quats"], gg["scales"], gg["opacities"], gg["colors"], vm.to(gpu_device),
+                          Ks.to(gpu_device), W, H, packed=True, render_mode="RGB+ED")
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+    mc = c[2]
+    for k in ("camera_ids", "gaussian_ids", "radii", "means2d", "depths", "conics"):
+        assert torch.equal(mc[k], mb[k]), k
