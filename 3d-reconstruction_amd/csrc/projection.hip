@@ -719,6 +719,7 @@ static int check_params(const gs_proj_params* p) {
   }
   if (nc + (p->depth_channel ? 1 : 0) > 4) return GS_ERR_UNSUPPORTED;
   if (nc + (p->depth_channel ? 1 : 0) < 1) return GS_ERR_INVALID_ARG;
+  if (p->sh_rows < 0 || p->sh_rows > 2) return GS_ERR_INVALID_ARG;
   return GS_OK;
 }
 
@@ -751,7 +752,7 @@ extern "C" int gs_projection_fwd(const gs_proj_params* p, const float* means, co
   // coefficient rows up front only when most of them will be used: from four cameras on (measured crossover on the
   // 5-camera rig at 1 M Gaussians: 1 camera 0.086 / 0.048 ms prefetched / on demand, 2: 0.090 / 0.076, 3: 0.095 / 0.101,
   // 4: 0.104 / 0.121, 5: 0.111 / 0.127; three neighbouring trajectory views see almost the same Gaussians: on demand)
-  const bool prefetch_rows = p->C >= 4;
+  const bool prefetch_rows = p->sh_rows == 0 ? p->C >= 4 : p->sh_rows == 1;
   switch (p->color_mode) {
     case GS_COLOR_NONE: GS_FWD_LAUNCH(GS_COLOR_NONE, 0); break;
     case GS_COLOR_N: GS_FWD_LAUNCH(GS_COLOR_N, 0); break;

@@ -42,6 +42,7 @@ class ProjParams(Structure):
         ("color_mode", c_int32), ("color_dim", c_int32),
         ("sh_degree", c_int32), ("sh_K", c_int32),
         ("depth_channel", c_int32),
+        ("sh_rows", c_int32),
     ]
 
 

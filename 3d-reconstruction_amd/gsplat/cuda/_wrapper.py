@@ -98,6 +98,9 @@ def _make_params(N, C, width, height, tile_size, eps2d, near_plane, far_plane, r
     p.color_mode, p.color_dim = color_mode, color_dim
     p.sh_degree, p.sh_K = (sh_degree if sh_degree is not None else 0), sh_K
     p.depth_channel = int(depth_channel)
+    # SH coefficient rows of the forward: 0 = by camera count; the trajectory harness asks for "on demand" (2): its
+    # neighbouring views see the same quarter of the Gaussians however many it renders per call
+    p.sh_rows = int(getattr(_tls, "sh_rows", 0))
     return p
 
 

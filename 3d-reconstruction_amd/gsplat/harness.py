@@ -56,6 +56,21 @@ def render_trajectory(means: Tensor, quats: Tensor, scales: Tensor, opacities: T
     raster_kwargs.setdefault("render_mode", "RGB")
     main = torch.cuda.current_stream(dev)
     copy = B.side_stream(dev)
+    from .cuda import _wrapper as W
+
+    prev_rows = getattr(W._tls, "sh_rows", 0)
+    W._tls.sh_rows = 2  # neighbouring views: coefficient rows on demand, whatever views_per_call is (gs_proj_params.sh_rows)
+    try:
+        _render_batches(means, quats, scales, opacities, colors, viewmats, Ks, width, height, sh_degree, views_per_call,
+                        mine, n_mine, as_uint8, out, backgrounds, raster_kwargs, main, copy)
+    finally:
+        W._tls.sh_rows = prev_rows
+    copy.synchronize()
+    return out, mine
+
+
+def _render_batches(means, quats, scales, opacities, colors, viewmats, Ks, width, height, sh_degree, views_per_call,
+                    mine, n_mine, as_uint8, out, backgrounds, raster_kwargs, main, copy) -> None:
     with torch.no_grad(), no_eval_cache():  # every batch is a new camera set: nothing to reuse
         for b0 in range(0, n_mine, views_per_call):
             idx = slice(mine.start + b0, mine.start + min(b0 + views_per_call, n_mine))
@@ -68,5 +83,3 @@ def render_trajectory(means: Tensor, quats: Tensor, scales: Tensor, opacities: T
             with torch.cuda.stream(copy):
                 out[b0:b0 + frames.shape[0]].copy_(frames, non_blocking=True)
             frames.record_stream(copy)
-    copy.synchronize()
-    return out, mine

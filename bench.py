@@ -257,7 +257,7 @@ def main():
     ap.add_argument("--height", type=int, default=None, help="default 375 (train, frames) / 1080 (render)")
     ap.add_argument("--frames", type=int, default=120)
     ap.add_argument("--views", type=int, default=600)
-    ap.add_argument("--views-per-call", type=int, default=3)
+    ap.add_argument("--views-per-call", type=int, default=4)
     ap.add_argument("--refine-interval", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=4)

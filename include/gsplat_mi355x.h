@@ -70,6 +70,10 @@ typedef struct gs_proj_params {
   int32_t color_dim;          /* channels of `colors` (SH: 3)    */
   int32_t sh_degree, sh_K;    /* GS_COLOR_SH only                */
   int32_t depth_channel;      /* 1: append depth after colours   */
+  int32_t sh_rows;            /* GS_COLOR_SH, forward only: when a Gaussian's coefficient row is requested.
+                                 0 = chosen by camera count (up front from four cameras on), 1 = up front (most rows get
+                                 used: a rig looking all around), 2 = at the first camera that sees the Gaussian (few
+                                 rows get used: one or two cameras, neighbouring views of a trajectory).  Speed only. */
 } gs_proj_params;
 
 int gs_version(void);

@@ -180,6 +180,15 @@ def test_entry_points_reject_bad_arguments_before_any_launch():
     assert L.gs_sh_fwd(10, 16, 5, P, P, None, P, None) == INVALID                 # degree > 4
     assert L.gs_sh_fwd(10, 4, 3, P, P, None, P, None) == INVALID                  # (3+1)^2 > K
     assert L.gs_sh_bwd(-1, 16, 3, P, P, None, P, P, None, None) == INVALID
+    pp = B.ProjParams(N=0, C=1, width=64, height=48, tile_size=16, tile_w=4, tile_h=3, eps2d=0.3, near_plane=0.01,
+                      far_plane=1e10, radius_clip=0.0, calc_compensations=0, color_mode=3, color_dim=3, sh_degree=3,
+                      sh_K=16, depth_channel=0, sh_rows=0)
+    fwd = lambda: L.gs_projection_fwd(ctypes.byref(pp), *([P] * 15), None)
+    assert fwd() == 0                                                             # N = 0: nothing to launch
+    pp.sh_rows = 3
+    assert fwd() == INVALID                                                       # sh_rows outside 0..2
+    pp.sh_rows, pp.tile_w = 2, 5
+    assert fwd() == INVALID                                                       # tile grid does not match the image
     assert L.gs_activate_fwd(10, 3, 3, P, P, P, P, P, None, P, 0, P, P, P, P, P, P, P, P, None) == INVALID  # K_rest < 15
     assert L.gs_activate_fwd(10, 15, 3, P, P, P, P, P, None, P, 3, P, P, P, P, P, P, P, P, None) == INVALID  # scale_mode
     assert L.gs_refine_gather_rows(10, 300, 0, P, P, None, P, P, None) == INVALID   # W > 256

@@ -45,3 +45,15 @@ def robust_rel_l2(got, ref, drop_frac=1e-3):
     err = (got - ref).pow(2).sum(1)
     keep = err.argsort()[: max(1, int(round(err.numel() * (1.0 - drop_frac))))]
     return float(err[keep].sum().sqrt() / (ref[keep].norm() + 1e-30))
+
+
+def assert_rerun_close(name, got, ref, max_bad_frac=1e-4):
+    """Two runs of the same decisions whose fp32 sums are taken in a different order (float atomics in the rasterizer
+    backward).  scratch/worst_row.py on the N=6000 case: one needle-shaped Gaussian (scales 1:12, |v_quats| ~ 100 from
+    cancelling terms) moves by 1e-2, 1e-4 of itself, between two orders of its atomic adds and alone decides the plain
+    rel-L2 (5e-7 when the order repeats, 7e-6..1e-5 when it does not; the same single row of 6000 is outside the
+    elementwise tolerance then).  So: 1e-5 with the 0.1 % worst rows left out, 1e-4 with them."""
+    frac, rel_l2, mx = close_report(name, got, ref, scale_atol=True)
+    assert frac <= max_bad_frac, f"{name}: {frac:.3e} of elements outside tolerance (max abs err {mx:.3e})"
+    rob = robust_rel_l2(got, ref) if got.dim() >= 1 and got.shape[0] >= 1000 else rel_l2
+    assert rob <= 1e-5 and rel_l2 <= 1e-4, f"{name}: rel_l2 {rel_l2:.3e} (robust {rob:.3e})"
