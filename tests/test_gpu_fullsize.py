@@ -18,7 +18,7 @@ import torch
 
 import oracle
 import synth_scene
-from util import assert_close, close_report
+from util import assert_close, assert_rerun_close, close_report
 
 pytestmark = pytest.mark.gpu
 
@@ -141,7 +141,7 @@ def test_config2_full_size(gpu_device):
     assert torch.equal(rc, rc2) and torch.equal(ra, ra2)
     ((rc2 * wc).sum() + (ra2 * wa).sum()).backward()
     for k, v in p.items():
-        assert_close(f"cfg2.rerun.v_{k}", v.grad, grads[k], scale_atol=True, max_bad_frac=1e-4, max_rel_l2=1e-5)
+        assert_rerun_close(f"cfg2.rerun.v_{k}", v.grad, grads[k])
 
     # camera-shard additivity: 5 single-camera calls, gradients summed == the batched call
     for v in p.values():
@@ -155,8 +155,8 @@ def test_config2_full_size(gpu_device):
         ((rcc * wc[c:c + 1]).sum() + (rac * wa[c:c + 1]).sum()).backward()
         absg_c.append(mc["means2d"].absgrad[0])
     for k, v in p.items():
-        assert_close(f"cfg2.shard.v_{k}", v.grad, grads[k], scale_atol=True, max_bad_frac=1e-4, max_rel_l2=1e-5)
-    assert_close("cfg2.shard.absgrad", torch.stack(absg_c), absg, scale_atol=True, max_bad_frac=1e-4, max_rel_l2=1e-5)
+        assert_rerun_close(f"cfg2.shard.v_{k}", v.grad, grads[k])
+    assert_rerun_close("cfg2.shard.absgrad", torch.stack(absg_c), absg)
 
 
 # ------------------------------------------------------------------------------------------------- configs[2]
