@@ -267,6 +267,18 @@ def test_projection_is_bitwise_the_same_alone_and_in_a_batch(gpu_device):
         seen += int(vis.sum())
         assert torch.equal(sp5[c][vis], sp1[0][vis]), f"camera {c}: records differ between the batch and the single call"
     assert seen > 1000
+    # ... nor on what the caller asks for in gs_proj_params.sh_rows (1 = up front, 2 = on demand), at any camera count
+    for c_n in (1, 3, 5):
+        got = []
+        for rows in (1, 2):
+            Wm._tls.sh_rows = rows
+            try:
+                got.append(project(vm[:c_n], Ks[:c_n]))
+            finally:
+                Wm._tls.sh_rows = 0
+        (sa, _, ra, ta), (sb, _, rb, tb) = got
+        assert torch.equal(ra, rb) and torch.equal(ta, tb)
+        assert torch.equal(sa[ta > 0], sb[tb > 0]), f"{c_n} cameras: records differ between sh_rows = 1 and 2"
 
 
 def test_isect_sort_offsets_bit_exact(gpu_device):
