@@ -78,7 +78,9 @@ typedef struct gs_proj_params {
 
 int gs_version(void);
 const char* gs_error_string(int status);
-/* hipMemsetAsync(ptr, 0, bytes) on `stream`: clears the gradient record gs_rasterize_bwd accumulates into. */
+/* Zeroes `bytes` at `ptr` on `stream`: clears the gradient record gs_rasterize_bwd accumulates into (a 16-B aligned
+ * buffer above 32 MiB by nontemporal stores, so that the zeros do not displace what the kernels beside it are reading;
+ * hipMemsetAsync otherwise). */
 int gs_fill_zero(void* ptr, int64_t bytes, void* stream);
 /* Rendered floats -> video frames as the reference converts them on the host
  * (/root/reference/3D-Reconstruction-main/models/video_utils.py:694-700): dst[i] = (uint8)(clip(src[i], 1e-6, 1 - 1e-6) * 255),
