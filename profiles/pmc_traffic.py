@@ -93,7 +93,9 @@ def main():
             expect = (2 * 4 * C * H * W * D + 2 * 4 * C * H * W) / 2
             out["calibration"]["read: rocblas dot, corrected/expected"] = round(v[1] * 2048 / expect, 3)
     for k, v in wr.items():
-        if "fillBufferAligned" in k:  # the gradient record's hipMemsetAsync: C*N*64 bytes per step (+ a few small fills)
+        if "fill_zero_nt_kernel" in k:  # the gradient record's fill (nontemporal stores): C*N*64 bytes per launch
+            out["calibration"]["write: gradient-record fill, counted/expected"] = round(v[1] * 1024 / (C * N * 64), 3)
+        if "fillBufferAligned" in k:  # (builds before the nontemporal fill: hipMemsetAsync, + a few small fills)
             steps = max([c for kk, (c, _) in wr.items() if "gs::projection_fwd_kernel" in kk] or [1])
             out["calibration"]["write: gradient-record memset, counted/expected"] = round(
                 v[1] * v[0] / steps * 1024 / (C * N * 64), 3)
