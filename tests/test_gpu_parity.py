@@ -281,6 +281,28 @@ def test_projection_is_bitwise_the_same_alone_and_in_a_batch(gpu_device):
         assert torch.equal(sa[ta > 0], sb[tb > 0]), f"{c_n} cameras: records differ between sh_rows = 1 and 2"
 
 
+def test_fill_zero_large_and_small(gpu_device):
+    """gs_fill_zero: buffers above 32 MiB go through the nontemporal fill kernel, the rest through hipMemsetAsync; either
+    way exactly `bytes` bytes are cleared and nothing around them."""
+    from gsplat import _backend as B
+
+    guard = 1024  # floats on either side that must keep their ones
+    for n_bytes in ((32 << 20) + 16, (32 << 20) + 4096 + 48, (48 << 20), (32 << 20), 4096, (32 << 20) + 4):
+        n = n_bytes // 4
+        buf = torch.ones(n + 2 * guard, device=gpu_device, dtype=torch.float32)
+        inner = buf[guard:guard + n]
+        assert inner.data_ptr() % 16 == 0
+        B.check(B.lib().gs_fill_zero(inner.data_ptr(), n_bytes, B.stream_handle(gpu_device)), "gs_fill_zero")
+        torch.cuda.synchronize()
+        assert float(inner.abs().max()) == 0.0, n_bytes
+        assert float(buf[:guard].min()) == 1.0 and float(buf[guard + n:].min()) == 1.0, n_bytes
+    # a 4-byte aligned start (not 16): the memset path, whatever the size
+    buf = torch.ones((40 << 20) // 4 + 8, device=gpu_device, dtype=torch.float32)
+    B.check(B.lib().gs_fill_zero(buf.data_ptr() + 4, 40 << 20, B.stream_handle(gpu_device)), "gs_fill_zero")
+    torch.cuda.synchronize()
+    assert float(buf[1:1 + (40 << 20) // 4].abs().max()) == 0.0 and float(buf[0]) == 1.0 and float(buf[-1]) == 1.0
+
+
 def test_isect_sort_offsets_bit_exact(gpu_device):
     """Integer stages are compared bit-for-bit: the oracle is fed the GPU's own fp32 means2d/radii/depths."""
     for (W, H, C, N) in [(160, 96, 2, 4096), (375, 250, 5, 20000), (33, 17, 1, 300)]:
