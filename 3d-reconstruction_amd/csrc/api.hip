@@ -24,8 +24,8 @@ extern "C" const char* gs_error_string(int status) {
 // takes more of the part away from the forward rasterizer it overlaps: 1.268-1.273 vs 1.262-1.264 ms per step.)
 namespace gs {
 // Large fills (the 320 MB gradient record, cleared on a side stream beside the forward rasterizer) go out as nontemporal
-// stores from one workgroup per CU: the zeros do not displace the splat records and tile lists the rasterizer is reading
-// from L2 / the Infinity Cache.  Same-box A/B at configs[1] (profiles/r02_ab_runs.txt item 30): step 1.122 -> 1.100 ms
+// stores from one workgroup per CU: the zeros are not allocated in the caches on their way to HBM (the neighbours' L2
+// miss traffic is unchanged; what they come back for stays in the Infinity Cache).  Same-box A/B at configs[1] (profiles/r02_ab_runs.txt item 30): step 1.122 -> 1.100 ms
 // against hipMemsetAsync; the same kernel with plain stores gains nothing.
 constexpr int64_t FILL_NT_MIN_BYTES = (int64_t)32 << 20;
 constexpr int FILL_NT_WGS = 256;

@@ -79,7 +79,7 @@ typedef struct gs_proj_params {
 int gs_version(void);
 const char* gs_error_string(int status);
 /* Zeroes `bytes` at `ptr` on `stream`: clears the gradient record gs_rasterize_bwd accumulates into (a 16-B aligned
- * buffer above 32 MiB by nontemporal stores, so that the zeros do not displace what the kernels beside it are reading;
+ * buffer above 32 MiB by nontemporal stores, so that the zeros are not allocated in the caches on their way to HBM;
  * hipMemsetAsync otherwise). */
 int gs_fill_zero(void* ptr, int64_t bytes, void* stream);
 /* Rendered floats -> video frames as the reference converts them on the host
