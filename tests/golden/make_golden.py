@@ -9,6 +9,14 @@
                           stages, G3 raster forward, G4 gradients of a fixed random linear loss.  PARITY UNPINNED w.r.t.
                           gsplat itself: these are the oracle's outputs, not gsplat's.
   sh_fp64.npz             G5: SH degree 0..4 forward + v_coeffs + v_dirs of the oracle.
+  losses_ref.npz          inputs + outputs (values and input gradients, fp64) of the REFERENCE's own loss file
+                          /root/reference/3D-Reconstruction-main/models/losses.py (numpy + torch only; imported from
+                          where it lies): SafeBCE forward / backward (:33-75; limit 0.1, inputs outside [0,1], the
+                          x == y gradient gate), safe_binary_cross_entropy / binary_cross_entropy "mean" (:77-83) on the
+                          masks of base.py:536-550, DepthLoss (:91-176) for l1 / l2 / smooth_l1 x normalize x inverse x
+                          the four reductions, two percentiles and an empty hit set, called as at base.py:553-557.
+                          Pins oracle/loss_ref.py (tests/test_oracle_cpu.py) and the HIP loss kernels
+                          (tests/test_gpu_losses.py).
 
     python tests/golden/make_golden.py
 """
@@ -26,6 +34,16 @@ import oracle  # noqa: E402
 import synth_scene  # noqa: E402
 
 REF_GEOMETRY = "/root/reference/3D-Reconstruction-main/utils/geometry.py"
+REF_LOSSES = "/root/reference/3D-Reconstruction-main/models/losses.py"
+
+DEPTH_CASES = [(t, n, i, r) for t in ("l1", "l2", "smooth_l1") for n in (False, True) for i in (False, True)
+               for r in ("mean_on_hit", "mean_on_hw", "sum", "none")]
+PERCENTILE_CASES = [("l1", False, False, "mean_on_hit", 0.95), ("l2", True, False, "sum", 0.5)]
+
+
+def depth_case_key(loss_type, normalize, inverse, reduction, percentile=None):
+    k = f"depth_{loss_type}_n{int(normalize)}_i{int(inverse)}_{reduction}"
+    return k if percentile is None else f"{k}_p{int(round(percentile * 100))}"
 
 
 def quat_golden():
@@ -89,8 +107,85 @@ def sh_golden():
     np.savez_compressed(os.path.join(HERE, "sh_fp64.npz"), **out)
 
 
+def losses_golden():
+    spec = importlib.util.spec_from_file_location("ref_losses", REF_LOSSES)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    H, W = 41, 57
+    g = torch.Generator().manual_seed(23)
+    opacity = torch.rand(H, W, 1, generator=g).clamp(1e-4, 1 - 1e-4)
+    opacity[0, :5] = 0.0    # exact 0 / 1: the clipped ends of both BCE forms, and x == y where the target agrees
+    opacity[1, :5] = 1.0
+    opacity_wild = opacity.clone()      # SafeBCE only: inputs outside [0, 1] (clipped in forward, losses.py:48)
+    opacity_wild[2, :9] = 1.0 + torch.rand(9, 1, generator=g) * 0.3
+    opacity_wild[3, :9] = -torch.rand(9, 1, generator=g) * 0.3
+    depth = torch.rand(H, W, 1, generator=g) * 90 + 0.05
+    depth[4, :6] = 0.0      # below the 1e-4 validity gate (losses.py:123)
+    sky = (torch.rand(H, W, generator=g) > 0.7).float()
+    sky[0, :5], sky[1, :5] = 1.0, 0.0   # targets 0 / 1 under the exact opacities above
+    valid = (torch.rand(H, W, generator=g) > 0.1).float()
+    valid[0, :3] = 1.0
+    valid[1, :3] = 1.0
+    lidar = torch.where(torch.rand(H, W, generator=g) > 0.6, torch.rand(H, W, generator=g) * 100, torch.zeros(H, W))
+    lidar[5, :7] = depth[5, :7, 0]      # exact hits: |d| = 0 rows of every loss type
+    lidar[6, :7] = depth[6, :7, 0] + 0.5    # |d| < 1 (smooth-l1's quadratic branch) ...
+    lidar[7, :7] = depth[7, :7, 0] - 3.0    # ... and > 1 whatever the random rows hold
+    out = dict(opacity=opacity.numpy(), opacity_wild=opacity_wild.numpy(), depth=depth.numpy(), sky=sky.numpy(),
+               valid=valid.numpy(), lidar=lidar.numpy(), limit=0.1, max_depth=80.0)
+    d = lambda t: t.double()
+
+    # SafeBCE itself, elementwise, with an upstream gradient (losses.py:41-75)
+    gen_y = (torch.rand(H, W, generator=g) > 0.5).double()
+    gen_y[2, :9] = (torch.arange(9) % 2).double()   # wild inputs against both targets
+    gen_y[3, :9] = (torch.arange(9) % 2).double()
+    go = torch.randn(H, W, generator=g).double()
+    x = d(opacity_wild[..., 0]).requires_grad_(True)
+    loss = ref.SafeBCE.apply(x, gen_y, 0.1)
+    loss.backward(go)
+    out.update(safe_y=gen_y.numpy(), safe_go=go.numpy(), safe_loss=loss.detach().numpy(), safe_grad_x=x.grad.numpy())
+
+    # the mask loss as base.py:536-550 calls either form
+    for name, op, fn in (("bce", opacity, lambda a, b: ref.binary_cross_entropy(a, b, reduction="mean")),
+                         ("safe_bce", opacity, lambda a, b: ref.safe_binary_cross_entropy(a, b, limit=0.1, reduction="mean")),
+                         ("safe_bce_wild", opacity_wild, lambda a, b: ref.safe_binary_cross_entropy(a, b, limit=0.1, reduction="mean"))):
+        o = d(op).requires_grad_(True)
+        gt_occupied = (1.0 - d(sky)) * d(valid)
+        pred_occupied = o.squeeze() * d(valid)
+        val = fn(pred_occupied, gt_occupied)
+        val.backward()
+        out[f"mask_{name}"] = val.detach().numpy()
+        out[f"mask_{name}_grad"] = o.grad.numpy()
+
+    # DepthLoss as base.py:553-557 calls it: hit mask = (lidar > 0) * valid
+    def run_depth(loss_type, normalize, inverse, reduction, percentile, lid):
+        fn = ref.DepthLoss(loss_type=loss_type, normalize=normalize, use_inverse_depth=inverse,
+                           depth_error_percentile=percentile, upper_bound=80.0, reduction=reduction)
+        p = d(depth).requires_grad_(True)
+        hit = (d(lid) > 0).double() * d(valid)
+        val = fn(p, d(lid), hit)
+        if reduction != "none" and val.requires_grad and torch.isfinite(val):
+            val.backward()
+        return val.detach().numpy(), (p.grad.numpy() if p.grad is not None else np.zeros(p.shape))
+
+    for (t, n, i, r) in DEPTH_CASES:
+        v, gr = run_depth(t, n, i, r, None, lidar)
+        k = depth_case_key(t, n, i, r)
+        out[k] = v
+        if r != "none":
+            out[k + "_grad"] = gr
+    for (t, n, i, r, pc) in PERCENTILE_CASES:
+        v, gr = run_depth(t, n, i, r, pc, lidar)
+        k = depth_case_key(t, n, i, r, pc)
+        out[k], out[k + "_grad"] = v, gr
+    for r in ("mean_on_hit", "mean_on_hw", "sum"):   # nothing hit: mean of an empty tensor is NaN, the sums are 0
+        v, _ = run_depth("l1", False, False, r, None, torch.zeros(H, W))
+        out[f"depth_empty_{r}"] = v
+    np.savez_compressed(os.path.join(HERE, "losses_ref.npz"), **out)
+
+
 if __name__ == "__main__":
     quat_golden()
+    losses_golden()
     pipeline_golden()
     sh_golden()
     for f in sorted(os.listdir(HERE)):

@@ -7,6 +7,10 @@
     exactly those tiles from the Gaussians in their lists, and the gradients of those Gaussians are compared; every
     other Gaussian's gradient must be exactly zero.
 
+  * configs[2] shape (3M composite Gaussians, one 1920x1280 camera, classic mode, [N,3] colours from the standalone
+    spherical_harmonics op as the reference calls it, vanilla.py:369-370 / base.py:393-408, ~5 % of the node opacities
+    exactly zero) on sampled tiles the same way, gradients through to the SH coefficients.
+
 PARITY UNPINNED against gsplat itself (oracle/__init__.py).  Bars as in tests/test_gpu_parity.py: 1e-5 abs + 1e-4 rel
 on the forward with the stated flip budget, gradients rel-L2 <= 5e-5 (~3x measured) with an elementwise budget."""
 import math
@@ -158,4 +162,98 @@ def test_config2_gradient_spot_check_on_sampled_tiles(gpu_device):
         rest[gd] = 0
         if float(rest.abs().max()) != 0.0:
             fails.append((k, "gradient outside the sampled tiles' Gaussians", float(rest.abs().max())))
+    assert not fails, fails
+
+
+def test_config3_gradient_spot_check_on_sampled_tiles(gpu_device):
+    """BASELINE configs[2] as the reference calls it: colours are pre-evaluated by the standalone op with detached view
+    directions, +0.5, clamped to [0, 1] (vanilla.py:366-370), rasterized in classic mode with absgrad (base.py:393-408)."""
+    from gsplat.cuda._wrapper import _camera_centers, spherical_harmonics
+    from gsplat.rendering import rasterization
+
+    dev = gpu_device
+    W, H, C = 1920, 1280, 1
+    sizes = [2_600_000, 250_000, 100_000, 7 * 6890]
+    N = sum(sizes)
+    g = synth_scene.make_gaussians(N, sh_degree=3, seed=7)
+    vm, Ks = synth_scene.make_cameras(1, W, H)
+    gen = torch.Generator().manual_seed(3)
+    zero = torch.rand(N, generator=gen) < 0.05
+    zero[: sizes[0]] = False
+    g["opacities"][zero] = 0.0
+    p = {k: v.to(dev).requires_grad_(True) for k, v in g.items()}
+    vmd = vm.to(dev)
+    dirs = (p["means"] - _camera_centers(vmd)[0]).detach()
+    rgb = torch.clamp(spherical_harmonics(3, dirs, p["colors"]) + 0.5, 0.0, 1.0)
+    rc, ra, meta = rasterization(p["means"], p["quats"], p["scales"], p["opacities"], rgb, vmd, Ks.to(dev), W, H,
+                                 near_plane=0.1, far_plane=1e10, packed=False, render_mode="RGB+ED", absgrad=True,
+                                 rasterize_mode="classic")
+    TW, TH = meta["tile_width"], meta["tile_height"]
+    assert TW * TH == 80 * 120
+    T = C * TW * TH
+    fids = meta["flatten_ids"].cpu().long()
+    offs = torch.cat([meta["isect_offsets"].reshape(-1).cpu().long(), torch.tensor([fids.numel()])])
+    lens = offs[1:] - offs[:-1]
+    pick = _pick_tiles(lens, C, TW, TH, 14, seed=9)
+    assert len(pick) >= 12
+
+    mask = torch.zeros(C, H, W, 1)
+    for t in pick:
+        ty, tx = (t % (TW * TH)) // TW, t % TW
+        mask[0, ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16] = 1.0
+    gen = torch.Generator().manual_seed(17)
+    wc = torch.randn(C, H, W, 4, generator=gen) * mask
+    wa = torch.randn(C, H, W, 1, generator=gen) * mask
+    meta["means2d"].retain_grad()
+    ((rc * wc.to(dev)).sum() + (ra * wa.to(dev)).sum()).backward()
+
+    lists = [fids[offs[t]:offs[t + 1]] for t in pick]
+    gauss = torch.unique(torch.cat(lists) % N)
+    M = gauss.numel()
+    sub = {k: g[k][gauss].double().requires_grad_(True) for k in g}
+    vm64, K64 = vm.double(), Ks.double()
+    radii_o, m2, depths, conics, _ = oracle.gsplat_ref.fully_fused_projection(
+        sub["means"], sub["quats"], sub["scales"], vm64, K64, W, H, 0.3, 0.1, 1e10, 0.0, calc_compensations=False)
+    m2.retain_grad()
+    campos = torch.linalg.inv(vm64)[0, :3, 3]
+    dirs_o = (sub["means"] - campos).detach()
+    rgb_o = torch.clamp(oracle.spherical_harmonics(3, dirs_o, sub["colors"]) + 0.5, 0.0, 1.0)
+    cols = torch.cat([rgb_o[None], depths[..., None]], -1)
+    opac = sub["opacities"][None, :].expand(C, -1)
+    szs = torch.zeros(T, dtype=torch.long)
+    szs[pick] = lens[pick]
+    offs_o = (torch.cumsum(szs, 0) - szs).reshape(C, TH, TW).to(torch.int32)
+    remap = torch.cat([torch.searchsorted(gauss, l % N) for l in lists]).to(torch.int32)
+    n_zero = int(zero[gauss].sum())
+    print(f"[parity] cfg2 spot check: {len(pick)} tiles, {int(szs.sum())} list entries, {M} Gaussians "
+          f"({n_zero} with zero opacity)")
+    assert n_zero > 0
+    rco, rao, _ = oracle.rasterize_to_pixels(m2, conics, cols, opac, W, H, 16, offs_o, remap)
+    rco = torch.cat([rco[..., :-1], rco[..., -1:] / rao.clamp(min=1e-10)], -1)
+    ((rco * wc.double()).sum() + (rao * wa.double()).sum()).backward()
+
+    sel = mask[..., 0] > 0
+    assert_close("cfg2.tiles.alphas", ra.detach().cpu()[sel], rao.detach()[sel], max_bad_frac=2e-3)
+    assert_close("cfg2.tiles.colors", rc.detach().cpu()[sel], rco.detach()[sel], max_bad_frac=2e-3)
+    gd = gauss.to(dev)
+    fails = []
+    for k in ["means", "quats", "scales", "opacities", "colors"]:
+        got = p[k].grad
+        frac, rel_l2, _ = close_report(f"cfg2.tiles.v_{k}", got[gd], sub[k].grad)
+        rob = robust_rel_l2(got[gd], sub[k].grad, 1e-3)
+        print(f"[parity] cfg2.tiles.v_{k}: rel_l2 without the 0.1 % worst rows {rob:.3e}")
+        if not (rel_l2 <= 1.5e-4 and rob <= 5e-5 and frac <= 1.5e-3):
+            fails.append((k, rel_l2, rob, frac))
+        rest = got.clone()
+        rest[gd] = 0
+        if float(rest.abs().max()) != 0.0:
+            fails.append((k, "gradient outside the sampled tiles' Gaussians", float(rest.abs().max())))
+    # the caller-visible 2-D gradient (base.py:282-286 reads it for densification)
+    frac, rel_l2, _ = close_report("cfg2.tiles.means2d.grad", meta["means2d"].grad[0][gd], m2.grad[0], scale_atol=True)
+    if not (rel_l2 <= 1.5e-4 and frac <= 1.5e-3):
+        fails.append(("means2d.grad", rel_l2, frac))
+    # a zero-opacity Gaussian: no colour gradient, finite everything
+    zd = zero.to(dev)
+    if float(p["colors"].grad[zd].abs().max()) != 0.0:
+        fails.append(("colour gradient on zero-opacity rows",))
     assert not fails, fails

@@ -283,3 +283,69 @@ def test_opacity_reset_in_place(gpu_device):
     reset_opacities(untouched, 0.9999)  # above these opacities: unchanged up to the fp32 logit(sigmoid(.)) round trip
     mid = raw.abs() < 6
     assert torch.allclose(untouched.cpu()[mid], raw[mid], rtol=1e-3, atol=1e-3)
+
+
+# ------------------------------------------------- against the REFERENCE's own models/losses.py (committed fixture)
+def _ref_fixture(dev):
+    import os
+
+    import numpy as np
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "losses_ref.npz"))
+    f = lambda k: torch.from_numpy(z[k]).float().to(dev)
+    return z, f
+
+
+@pytest.mark.parametrize("name,op_key,kind", [("bce", "opacity", "bce"), ("safe_bce", "opacity", "safe_bce"),
+                                              ("safe_bce_wild", "opacity_wild", "safe_bce")])
+def test_mask_loss_matches_reference_fixture(gpu_device, name, op_key, kind):
+    """The HIP mask term against values and gradients the reference's binary_cross_entropy / safe_binary_cross_entropy
+    (models/losses.py:33-83) produced in fp64 on the same maps (tests/golden/make_golden.py::losses_golden)."""
+    from gsplat.losses import pixel_losses
+
+    z, f = _ref_fixture(gpu_device)
+    og = f(op_key).requires_grad_(True)
+    out = pixel_losses(og, None, f("sky"), f("valid"), None, opacity_loss_type=kind)
+    out["sky_bce"].backward()
+    ref, ref_g = float(z[f"mask_{name}"]), torch.from_numpy(z[f"mask_{name}_grad"])
+    assert abs(float(out["sky_bce"]) - ref) <= 2e-5 * max(1.0, abs(ref)), (float(out["sky_bce"]), ref)
+    err = float((og.grad.cpu().double() - ref_g).abs().max())
+    assert err <= 1e-4 * float(ref_g.abs().max()) + 1e-12, (err, float(ref_g.abs().max()))
+
+
+def test_depth_loss_matches_reference_fixture(gpu_device):
+    """Every DepthLoss setting of the reference (models/losses.py:91-176: 3 types x normalize x inverse x 4 reductions,
+    two percentiles, an empty hit set) against the reference's own fp64 outputs."""
+    import numpy as np
+
+    from gsplat.losses import depth_error_map, pixel_losses
+    from util import DEPTH_CASES, PERCENTILE_CASES, depth_case_key
+
+    dev = gpu_device
+    z, f = _ref_fixture(dev)
+    md = float(z["max_depth"])
+    n_checked = 0
+    for (ty, n, i, r, pc) in [c + (None,) for c in DEPTH_CASES] + PERCENTILE_CASES:
+        k = depth_case_key(ty, n, i, r, pc)
+        ref = np.asarray(z[k])
+        if r == "none":
+            m = depth_error_map(f("depth"), f("lidar"), f("valid"), md, ty, n, i).cpu().reshape(-1)
+            got = m[m >= 0].double()
+            assert got.numel() == ref.size, k
+            scale = float(np.abs(ref).max())
+            assert float((got - torch.from_numpy(ref)).abs().max()) <= 2e-5 * max(1.0, scale), k
+            continue
+        dg = f("depth").requires_grad_(True)
+        out = pixel_losses(f("opacity"), dg, None, f("valid"), f("lidar"), md, depth_loss_type=ty, normalize=n,
+                           inverse_depth=i, reduction=r, depth_error_percentile=pc)
+        out["depth_l1"].backward()
+        assert abs(float(out["depth_l1"]) - float(ref)) <= 1e-4 * max(1.0, abs(float(ref))), (k, float(out["depth_l1"]), float(ref))
+        ref_g = torch.from_numpy(z[k + "_grad"])
+        err = float((dg.grad.cpu().double() - ref_g).abs().max())
+        assert err <= 1e-4 * float(ref_g.abs().max()) + 1e-12, (k, err, float(ref_g.abs().max()))
+        n_checked += 1
+    assert n_checked == 38
+    for r in ("mean_on_hit", "mean_on_hw", "sum"):
+        out = pixel_losses(f("opacity"), f("depth"), None, f("valid"), torch.zeros_like(f("lidar")), md, reduction=r)
+        ref = float(z[f"depth_empty_{r}"])
+        assert (np.isnan(ref) and bool(torch.isnan(out["depth_l1"]))) or float(out["depth_l1"]) == ref, r

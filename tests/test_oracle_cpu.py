@@ -194,3 +194,64 @@ def test_projection_gradcheck_fp64():
         return m2d, d, con
 
     assert torch.autograd.gradcheck(f, (means, quats, scales), eps=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------ the loss oracle against the reference's own file
+def _loss_fixture():
+    z = np.load(os.path.join(GOLD, "losses_ref.npz"))
+    t = lambda k: torch.from_numpy(z[k]).double()
+    return z, t
+
+
+def test_loss_oracle_safe_bce_matches_reference_fixture():
+    """oracle/loss_ref.py::_SafeBCE against outputs of the reference's SafeBCE (models/losses.py:33-75): forward map and
+    input gradient, inputs outside [0, 1], limit 0.1, the x == y gate."""
+    from oracle import loss_ref as L
+
+    z, t = _loss_fixture()
+    x = t("opacity_wild")[..., 0].requires_grad_(True)
+    loss = L._SafeBCE.apply(x, t("safe_y"), float(z["limit"]))
+    loss.backward(t("safe_go"))
+    assert torch.allclose(loss.detach(), t("safe_loss"), rtol=1e-13, atol=1e-14)
+    assert torch.allclose(x.grad, t("safe_grad_x"), rtol=1e-13, atol=1e-14)
+    gate = (x.detach().clip(0, 1) == t("safe_y"))
+    assert int(gate.sum()) > 0 and float(x.grad[gate].abs().max()) == 0.0
+
+
+def test_loss_oracle_mask_terms_match_reference_fixture():
+    """mask_loss (base.py:536-550) with binary_cross_entropy / safe_binary_cross_entropy (losses.py:77-83)."""
+    from oracle import loss_ref as L
+
+    z, t = _loss_fixture()
+    for name, op_key, kind in (("bce", "opacity", "bce"), ("safe_bce", "opacity", "safe_bce"),
+                               ("safe_bce_wild", "opacity_wild", "safe_bce")):
+        o = t(op_key).requires_grad_(True)
+        val = L.mask_loss(o, t("sky"), t("valid"), kind)
+        val.backward()
+        assert abs(float(val.detach()) - float(z[f"mask_{name}"])) <= 1e-13, name
+        assert torch.allclose(o.grad, t(f"mask_{name}_grad"), rtol=1e-12, atol=1e-15), name
+
+
+def test_loss_oracle_depth_loss_matches_reference_fixture():
+    """depth_loss against the reference's DepthLoss (losses.py:91-176) in all 48 type x normalize x inverse x reduction
+    settings, two percentiles, and the empty hit set."""
+    from oracle import loss_ref as L
+    from util import DEPTH_CASES, PERCENTILE_CASES, depth_case_key
+
+    z, t = _loss_fixture()
+    md = float(z["max_depth"])
+    cases = [c + (None,) for c in DEPTH_CASES] + PERCENTILE_CASES
+    for (ty, n, i, r, pc) in cases:
+        p = t("depth").requires_grad_(True)
+        val = L.depth_loss(p, t("lidar"), t("valid"), ty, n, i, pc, md, r)
+        k = depth_case_key(ty, n, i, r, pc)
+        ref = torch.from_numpy(np.asarray(z[k])).double()
+        assert val.shape == ref.shape, k
+        assert torch.allclose(val.detach(), ref, rtol=1e-12, atol=1e-14), k
+        if r != "none":
+            val.backward()
+            assert torch.allclose(p.grad, t(k + "_grad"), rtol=1e-12, atol=1e-16), k
+    for r in ("mean_on_hit", "mean_on_hw", "sum"):
+        val = L.depth_loss(t("depth"), torch.zeros_like(t("lidar")), t("valid"), "l1", False, False, None, md, r)
+        ref = float(z[f"depth_empty_{r}"])
+        assert (np.isnan(ref) and bool(torch.isnan(val))) or float(val) == ref, r

@@ -57,3 +57,15 @@ def assert_rerun_close(name, got, ref, max_bad_frac=1e-4):
     assert frac <= max_bad_frac, f"{name}: {frac:.3e} of elements outside tolerance (max abs err {mx:.3e})"
     rob = robust_rel_l2(got, ref) if got.dim() >= 1 and got.shape[0] >= 1000 else rel_l2
     assert rob <= 1e-5 and rel_l2 <= 1e-4, f"{name}: rel_l2 {rel_l2:.3e} (robust {rob:.3e})"
+
+
+# keys of tests/golden/losses_ref.npz (written by tests/golden/make_golden.py::losses_golden from the reference's own
+# models/losses.py)
+DEPTH_CASES = [(t, n, i, r) for t in ("l1", "l2", "smooth_l1") for n in (False, True) for i in (False, True)
+               for r in ("mean_on_hit", "mean_on_hw", "sum", "none")]
+PERCENTILE_CASES = [("l1", False, False, "mean_on_hit", 0.95), ("l2", True, False, "sum", 0.5)]
+
+
+def depth_case_key(loss_type, normalize, inverse, reduction, percentile=None):
+    k = f"depth_{loss_type}_n{int(normalize)}_i{int(inverse)}_{reduction}"
+    return k if percentile is None else f"{k}_p{int(round(percentile * 100))}"
