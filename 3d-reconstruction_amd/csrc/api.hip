@@ -1,5 +1,6 @@
 // Version / error-string entry points of libgsplat_mi355x.so.
 #include <chrono>
+#include <mutex>
 #include "gs_common.hpp"
 
 extern "C" int gs_version(void) { return 100; }  // 0.1.0 (round 1)
@@ -11,10 +12,45 @@ extern "C" const char* gs_error_string(int status) {
     case GS_ERR_UNSUPPORTED: return "gsplat_mi355x: unsupported configuration";
     case GS_ERR_WORKSPACE: return "gsplat_mi355x: workspace too small";
     case GS_ERR_NOT_POSTED: return "gsplat_mi355x: the kernels did not post their results";
+    case GS_ERR_CONTRACT: return "gsplat_mi355x: a kernel found its inputs violating the entry point's precondition "
+                                 "(tile_order / size_classes do not describe these lists); outputs of that call are invalid";
     default: break;
   }
   if (status > 0) return hipGetErrorString((hipError_t)status);
   return "gsplat_mi355x: unknown error";
+}
+
+// ---- contract flag (gs_common.hpp): one int32 of pinned coherent host memory for the life of the process
+static int32_t* g_contract_host = nullptr;
+static int32_t* g_contract_dev = nullptr;
+static std::once_flag g_contract_once;
+
+int32_t* gs_contract_flag_device() {
+  std::call_once(g_contract_once, [] {
+    void* h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+      (void)hipGetLastError();
+      return;
+    }
+    *reinterpret_cast<int32_t*>(h) = 0;
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return; }
+    g_contract_host = reinterpret_cast<int32_t*>(h);
+    g_contract_dev = reinterpret_cast<int32_t*>(d);
+  });
+  return g_contract_dev;
+}
+
+int gs_contract_take() {
+  if (!g_contract_host) return 0;
+  return (int)__atomic_exchange_n(g_contract_host, (int32_t)0, __ATOMIC_ACQ_REL);
+}
+
+extern "C" int gs_contract_status(int32_t clear) {
+  if (!g_contract_host) return GS_OK;
+  const int32_t v = clear ? __atomic_exchange_n(g_contract_host, (int32_t)0, __ATOMIC_ACQ_REL)
+                          : __atomic_load_n(g_contract_host, __ATOMIC_ACQUIRE);
+  return v ? GS_ERR_CONTRACT : GS_OK;
 }
 
 // Zero `bytes` bytes at `ptr` on `stream` (hipMemsetAsync).  The gradient record the rasterizer's backward accumulates

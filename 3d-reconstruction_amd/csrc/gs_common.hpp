@@ -16,6 +16,15 @@
     if (e__ != hipSuccess) return (int)e__;       \
   } while (0)
 
+// ---- contract flag (api.hip) ------------------------------------------------------------------------------------
+// A kernel that finds its inputs violating an entry point's documented precondition (not a bug it can compute through)
+// raises this process-wide flag -- one int32 in pinned, coherent host memory, written with a system-scope store -- and
+// leaves its outputs in a state no later kernel faults on.  Host side: the entry points of the same family look at the
+// flag when they are called (a plain host load, no synchronisation) and return GS_ERR_CONTRACT once, clearing it;
+// gs_contract_status() reads it on demand.  NULL from gs_contract_flag_device() (allocation failed) = no reporting.
+int32_t* gs_contract_flag_device();   // device-visible address for kernel arguments
+int gs_contract_take();               // host: current code (0 = none), cleared by the read
+
 namespace gs {
 
 constexpr int REC = GS_REC;  // floats per splat record

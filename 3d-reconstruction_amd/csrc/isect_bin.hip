@@ -913,7 +913,7 @@ __global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(int32_t T, int32_
                                                                const int32_t* __restrict__ size_classes, uint2* pairs,
                                                                int64_t* isect_ids, int32_t* flatten_ids,
                                                                const int32_t* sel, int32_t sel_mode,
-                                                               int32_t* sorted_cnt) {
+                                                               int32_t* sorted_cnt, int32_t* contract_flag) {
   // sel != NULL restricts the launch to the tiles with sel[tile] < 0 (sel_mode 0: segments the front sort deferred)
   // or sel[tile] != 0 (sel_mode 1: tiles the rasterizer flagged); sorted_cnt[tile] = n marks a segment fully sorted
   constexpr int THREADS = WAVES * 64;
@@ -983,6 +983,17 @@ __global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(int32_t T, int32_
         isect_ids[start + i] = key_hi | (int64_t)e.x;
         flatten_ids[start + i] = (int32_t)e.y;
       }
+    } else {
+      // The list does not fit this class's buffer: tile_order / size_classes do not describe these lists (precondition
+      // in the header).  Never leave the segment's ids unwritten -- the rasterizer would gather through whatever the
+      // allocation held: hand out the list's own ids unsorted and raise the contract flag.
+      for (int i = threadIdx.x; i < n; i += THREADS) {
+        const uint2 e = pairs[start + i];
+        if (isect_ids) isect_ids[start + i] = key_hi | (int64_t)e.x;
+        flatten_ids[start + i] = (int32_t)e.y;
+      }
+      if (contract_flag && threadIdx.x == 0)
+        __hip_atomic_store(contract_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (sorted_cnt && threadIdx.x == 0) sorted_cnt[tile] = n;
     __syncthreads();
@@ -1320,6 +1331,7 @@ static int tile_sort_impl(int32_t C, int32_t tile_w, int32_t tile_h, const int32
                           const int32_t* tile_order, const int32_t* size_classes, uint64_t* pairs, int64_t* isect_ids,
                           int32_t* flatten_ids, const int32_t* sch, void* stream) {
   if (C < 1 || tile_w < 1 || tile_h < 1 || n_isects < 0) return GS_ERR_INVALID_ARG;
+  if (gs_contract_take()) return GS_ERR_CONTRACT;
   if (n_isects == 0) return GS_OK;
   if (n_isects >= ((int64_t)1 << 31)) return GS_ERR_UNSUPPORTED;
   if (!isect_offsets || !pairs || !flatten_ids) return GS_ERR_INVALID_ARG;
@@ -1331,7 +1343,8 @@ static int tile_sort_impl(int32_t C, int32_t tile_w, int32_t tile_h, const int32
   const int64_t n_tiles = (int64_t)C * T;
   hipStream_t s = (hipStream_t)stream;
   uint2* pr = reinterpret_cast<uint2*>(pairs);
-#define GS_TS_ARGS T, tile_n_bits, n_tiles, isect_offsets, n_isects, tile_order, size_classes, pr, isect_ids, flatten_ids, (const int32_t*)nullptr, 0, (int32_t*)nullptr
+  int32_t* cf = gs_contract_flag_device();
+#define GS_TS_ARGS T, tile_n_bits, n_tiles, isect_offsets, n_isects, tile_order, size_classes, pr, isect_ids, flatten_ids, (const int32_t*)nullptr, 0, (int32_t*)nullptr, cf
   if (tile_order && size_classes) {
     // longest lists first; grids are persistent and sized to the LDS-limited residency of each class; the short
     // classes run 4 / 2 waves per segment (one wave each left 8 waves per CU: 0.136 -> 0.110 ms for the chain)
@@ -1372,6 +1385,7 @@ static int tile_sort_geom(int32_t C, int32_t tile_w, int32_t tile_h, int64_t n_i
   *T = tile_w * tile_h;
   *tile_n_bits = gs::bin_ilog2_floor(*T) + 1;
   if (32 + *tile_n_bits + gs::bin_ilog2_floor(C) + 1 > 64) return GS_ERR_UNSUPPORTED;
+  if (gs_contract_take()) return GS_ERR_CONTRACT;
   return GS_OK;
 }
 
@@ -1390,6 +1404,7 @@ static int tile_sort_front_impl(int32_t C, int32_t tile_w, int32_t tile_h, const
   if (!isect_ids && !ts_ids_optional(tile_order, size_classes, sch, n_tiles)) return GS_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
   uint2* pr = reinterpret_cast<uint2*>(pairs);
+  int32_t* cf = gs_contract_flag_device();
 #define GS_TSF_ARGS T, tile_n_bits, n_tiles, isect_offsets, n_isects, tile_order, size_classes, pr, isect_ids, flatten_ids
   if (!(ts_class_empty(sch, 0, n_tiles) && ts_class_empty(sch, 1, n_tiles))) {  // any tile with more than TSF_MIN entries
     hipLaunchKernelGGL((gs::tile_sort_front_kernel<4>), dim3(256 * 6), dim3(256), 0, s, T, tile_n_bits, n_tiles,
@@ -1398,18 +1413,18 @@ static int tile_sort_front_impl(int32_t C, int32_t tile_w, int32_t tile_h, const
     // segments the front kernel deferred (sorted_counts < 0): whole-segment sort, as gs_isect_tile_sort does
     if (!ts_class_empty(sch, 0, n_tiles))
       hipLaunchKernelGGL((gs::tile_sort_kernel<6144, 0, 16>), dim3(256), dim3(1024), 0, s, GS_TSF_ARGS,
-                         (const int32_t*)sorted_counts, 0, sorted_counts);
+                         (const int32_t*)sorted_counts, 0, sorted_counts, cf);
     if (!ts_class_empty(sch, 1, n_tiles))
       hipLaunchKernelGGL((gs::tile_sort_kernel<2048, 1, GS_TS_W1>), dim3(256 * 3), dim3(64 * GS_TS_W1), 0, s, GS_TSF_ARGS,
-                         (const int32_t*)sorted_counts, 0, sorted_counts);
+                         (const int32_t*)sorted_counts, 0, sorted_counts, cf);
   }
   // short segments: sorted whole (sorted_counts was pre-filled with the list lengths by the caller)
   if (!ts_class_empty(sch, 2, n_tiles))
     hipLaunchKernelGGL((gs::tile_sort_kernel<1024, 2, GS_TS_W2>), dim3(256 * GS_TS_G2), dim3(64 * GS_TS_W2), 0, s,
-                       GS_TSF_ARGS, (const int32_t*)nullptr, 0, (int32_t*)nullptr);
+                       GS_TSF_ARGS, (const int32_t*)nullptr, 0, (int32_t*)nullptr, cf);
   if (!ts_class_empty(sch, 3, n_tiles))
     hipLaunchKernelGGL((gs::tile_sort_kernel<512, 3, GS_TS_W3>), dim3(256 * GS_TS_G3), dim3(64 * GS_TS_W3), 0, s,
-                       GS_TSF_ARGS, (const int32_t*)nullptr, 0, (int32_t*)nullptr);
+                       GS_TSF_ARGS, (const int32_t*)nullptr, 0, (int32_t*)nullptr, cf);
   GS_CHECK_LAUNCH();
   return GS_OK;
 }
@@ -1444,12 +1459,13 @@ static int tile_sort_redo_impl(int32_t C, int32_t tile_w, int32_t tile_h, const 
   if (!isect_ids && !ts_ids_optional(tile_order, size_classes, sch, n_tiles)) return GS_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
   uint2* pr = reinterpret_cast<uint2*>(pairs);
+  int32_t* cf = gs_contract_flag_device();
   if (!ts_class_empty(sch, 0, n_tiles))
     hipLaunchKernelGGL((gs::tile_sort_kernel<6144, 0, 16>), dim3(256), dim3(1024), 0, s, GS_TSF_ARGS, redo_flags, 1,
-                       sorted_counts);
+                       sorted_counts, cf);
   if (!ts_class_empty(sch, 1, n_tiles))
     hipLaunchKernelGGL((gs::tile_sort_kernel<2048, 1, GS_TS_W1>), dim3(256 * 3), dim3(64 * GS_TS_W1), 0, s, GS_TSF_ARGS, redo_flags, 1,
-                       sorted_counts);
+                       sorted_counts, cf);
 #undef GS_TSF_ARGS
   GS_CHECK_LAUNCH();
   return GS_OK;

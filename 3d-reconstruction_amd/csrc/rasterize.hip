@@ -619,6 +619,7 @@ extern "C" int gs_rasterize_fwd(int32_t C, int32_t width, int32_t height, int32_
   if ((sorted_counts || redo_pass) && !redo_flags) return GS_ERR_INVALID_ARG;
   if (opacity_override && n_per_camera < 1) return GS_ERR_INVALID_ARG;
   if (n_isects > 0 && (!splats || !flatten_ids)) return GS_ERR_INVALID_ARG;
+  if (gs_contract_take()) return GS_ERR_CONTRACT;  // a sort kernel found lists its tile_order did not describe
   const int TW = (width + 15) / 16, TH = (height + 15) / 16;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(tile_order ? (unsigned)(C * TW * TH) : gs::raster_grid((unsigned)(C * TW * TH))), block(64);

@@ -71,6 +71,7 @@ _SIGNATURES = {
     "gs_stream_synchronize": (ctypes.c_int, [_P]),
     "gs_host_post_alloc": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), c_int64]),
     "gs_host_post_free": (ctypes.c_int, [_P]),
+    "gs_contract_status": (ctypes.c_int, [c_int32]),
     "gs_host_post_wait": (ctypes.c_int, [_P, _P, c_int32, _P]),
     "gs_visibility_prefix": (ctypes.c_int, [c_int32, c_int32, _P, _P, _P, _P, c_int64, _P]),
     "gs_isect_bin_build": (ctypes.c_int, [c_int32] * 7 + [_P] * 5 + [c_int64, _P, _P, c_int32, _P, _P, _P, _P, _P, _P]),

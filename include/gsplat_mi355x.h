@@ -53,6 +53,7 @@ extern "C" {
 #define GS_ERR_UNSUPPORTED (-2)
 #define GS_ERR_WORKSPACE (-3)
 #define GS_ERR_NOT_POSTED (-4) /* gs_host_post_wait: the stream finished without the kernels having posted */
+#define GS_ERR_CONTRACT (-5)   /* a kernel found device-side inputs violating a documented precondition (below) */
 
 /* colour source of gs_projection_fwd/_bwd */
 #define GS_COLOR_NONE 0 /* no colour input (render_mode "D"/"ED")                    */
@@ -298,6 +299,19 @@ int gs_isect_tile_sort(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t*
                        const int32_t* size_classes /* its size_classes output (device int32[3]), or NULL */,
                        uint64_t* pairs, int64_t* isect_ids /* out [n_isects] */, int32_t* flatten_ids /* out */,
                        void* stream);
+
+/* PRECONDITION of every gs_isect_tile_sort* entry point given a tile_order / size_classes pair: the pair must be the
+ * output of gs_raster_tile_order (or gs_isect_bin_prepare) BY LIST LENGTH for exactly these isect_offsets -- the sort
+ * launches one kernel per contiguous size class (lists > 2048 | 1025..2048 | 513..1024 | <= 512 entries) and each
+ * class sorts in an LDS buffer of its class's capacity.  An order made from other lengths (the backward's order by
+ * walked length, another call's lists) breaks that.  The kernels check it: a list longer than its class's capacity is
+ * NOT sorted -- its flatten_ids segment receives the list's ids in arrival order (valid ids, so the rasterizer reads
+ * wrong-ordered but in-bounds records) -- and the process-wide contract flag is raised.  The next call of one of these
+ * entry points, of gs_rasterize_fwd[_front], or of gs_contract_status returns GS_ERR_CONTRACT once and clears the flag
+ * (asynchronous, like a sticky stream error: the call that returns it is not necessarily the one that caused it;
+ * synchronise the stream before gs_contract_status to attribute it).  No reference counterpart (gsplat's radix sort has
+ * no such precondition). */
+int gs_contract_status(int32_t clear /* 1: reset the flag */);
 
 /* Front-only variant of gs_isect_tile_sort (no reference counterpart: gsplat sorts every key).  Segments longer than
  * 1024 entries get only their leading >= k_target entries (1 <= k_target <= 1024) sorted and written to

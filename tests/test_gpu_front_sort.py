@@ -138,3 +138,58 @@ def test_front_sort_renders_identically(gpu_device, opac, expect_redo):
         a, b = g1[k].double(), g0[k].double()
         rel = float((a - b).norm() / (b.norm() + 1e-30))
         assert rel < 1e-5, (k, rel)
+
+
+def test_misclassed_tile_order_raises_the_contract_flag_and_does_not_fault(gpu_device):
+    """include/gsplat_mi355x.h, precondition of gs_isect_tile_sort*: tile_order / size_classes must describe these lists.
+    A 3000-entry list handed to the <= 512 class (size_classes all zero) must not be left unwritten (the rasterizer
+    would gather through uninitialised ids): its ids come out unsorted but valid, the contract flag is raised, the next
+    sort call returns GS_ERR_CONTRACT once, and the call after that works."""
+    from gsplat import _backend as B
+
+    dev = gpu_device
+    L = B.lib()
+    TW, TH, C = 4, 2, 1
+    lens = np.array([40, 3000, 0, 700, 12, 513, 1, 90], np.int64)
+    n = int(lens.sum())
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+    rng = np.random.default_rng(5)
+    depth_bits = rng.random(n, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    ids = rng.integers(0, 50_000, n).astype(np.uint64)
+    pairs_np = (ids << np.uint64(32)) | depth_bits  # uint2 {x = depth bits, y = id} as one little-endian u64
+    t = lambda a, dt: torch.from_numpy(a).to(dev).to(dt)
+    offsets = t(offs, torch.int32)
+    order = torch.arange(8, device=dev, dtype=torch.int32)
+    good_order = t(np.argsort(-lens, kind="stable").astype(np.int32), torch.int32)
+    good_classes = t(np.array([(lens > 2048).sum(), (lens > 1024).sum(), (lens > 512).sum()], np.int32), torch.int32)
+    bad_classes = torch.zeros(3, device=dev, dtype=torch.int32)  # "every list has <= 512 entries"
+
+    def sort(order_t, classes_t):
+        pairs = torch.from_numpy(pairs_np.view(np.int64)).to(dev)
+        keys = torch.full((n,), -1, device=dev, dtype=torch.int64)
+        fl = torch.full((n,), -7, device=dev, dtype=torch.int32)  # poison: an unwritten id is out of every range
+        with B.device_guard(dev):
+            st = L.gs_isect_tile_sort(C, TW, TH, B.ptr(offsets), n, B.ptr(order_t), B.ptr(classes_t), B.ptr(pairs),
+                                      B.ptr(keys), B.ptr(fl), B.stream_handle(dev))
+        torch.cuda.synchronize()
+        return st, keys.cpu().numpy(), fl.cpu().numpy()
+
+    assert L.gs_contract_status(1) in (0, -5)  # start from a clear flag
+    st, keys, fl = sort(good_order, good_classes)
+    assert st == 0 and L.gs_contract_status(0) == 0
+    for a, m in zip(offs, lens):  # reference order: (depth bits, id) ascending inside every list
+        seg = np.lexsort((ids[a:a + m], depth_bits[a:a + m]))
+        assert np.array_equal(fl[a:a + m].astype(np.uint64), ids[a:a + m][seg])
+
+    st, keys, fl_bad = sort(order, bad_classes)
+    assert st == 0                                    # asynchronous: the launch itself is fine
+    assert (fl_bad >= 0).all() and (fl_bad < 50_000).all(), "a list was left unwritten"
+    for a, m in zip(offs, lens):                      # every list holds exactly its own ids, sorted or not
+        assert np.array_equal(np.sort(fl_bad[a:a + m].astype(np.uint64)), np.sort(ids[a:a + m]))
+    assert L.gs_contract_status(0) == -5              # GS_ERR_CONTRACT, still set
+    st, _, _ = sort(good_order, good_classes)
+    assert st == -5                                   # reported once by the next entry point ...
+    with pytest.raises(RuntimeError, match="precondition"):
+        B.check(st, "gs_isect_tile_sort")
+    st, _, fl2 = sort(good_order, good_classes)
+    assert st == 0 and np.array_equal(fl2, fl)        # ... and cleared
