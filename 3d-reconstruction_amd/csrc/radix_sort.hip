@@ -266,11 +266,18 @@ static __device__ __align__(256) unsigned char scratch[RS_STATIC_BYTES];
 static void* g_scratch_ptr[RS_MAX_DEVICES];  // per device: address of that device's copy of `scratch`
 static std::mutex g_scratch_mutex;
 
-// Address of the current device's `scratch` (looked up once per device, with that device current).
-static int rs_static_scratch(void** out) {
+// Address of the current device's `scratch` (looked up once per device, with that device current).  The stream's
+// device must be the current one: the launches go to the stream's device, and another device's copy of the array
+// lives at another address (a peer write, or a fault).
+static int rs_static_scratch(void** out, hipStream_t stream) {
   int dev = -1;
   GS_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= RS_MAX_DEVICES) return GS_ERR_UNSUPPORTED;
+  if (stream) {
+    int sdev = -1;
+    GS_HIP(hipStreamGetDevice(stream, &sdev));
+    if (sdev != dev) return GS_ERR_INVALID_ARG;
+  }
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
   if (!g_scratch_ptr[dev]) {
     void* ptr = nullptr;
@@ -288,11 +295,13 @@ extern "C" int gs_radix_sort_pairs_u64_u32_static(int64_t n, int32_t begin_bit, 
   if (n < 0 || begin_bit < 0 || end_bit < begin_bit || end_bit > 64 || !result_in_b_host) return GS_ERR_INVALID_ARG;
   *result_in_b_host = 0;
   if (n > RS_STATIC_MAX_N) return GS_ERR_WORKSPACE;  // beyond the static table: use the workspace entry points
+  // (before the empty-input return: a call with n == 0 is the warm-up that resolves this device's scratch address --
+  // the first lookup may load the code object and is not for a stream under capture)
+  void* ptr = nullptr;
+  const int st = rs_static_scratch(&ptr, (hipStream_t)stream);
+  if (st != GS_OK) return st;
   if (n == 0 || end_bit == begin_bit) return GS_OK;
   if (!keys_a || !vals_a || !keys_b || !vals_b) return GS_ERR_INVALID_ARG;
-  void* ptr = nullptr;
-  const int st = rs_static_scratch(&ptr);
-  if (st != GS_OK) return st;
   uint32_t* table = (uint32_t*)ptr;
   uint32_t* totals = (uint32_t*)((char*)ptr + RS_STATIC_TABLE_BYTES);
   return rs_run(n, nullptr, begin_bit, end_bit, keys_a, vals_a, keys_b, vals_b, table, totals, result_in_b_host,

@@ -149,14 +149,16 @@ class _ProjectSplats(torch.autograd.Function):
         # the dense [C,N,2] means2d is what gradients hang on and what a dense `meta` shows; a caller that wants neither
         # (packed, no gradients: the render-only harness) sets _tls.skip_means2d and the 8 bytes per (camera, Gaussian)
         # are not written (the records hold the means of the visible rows)
-        skip_m2d = getattr(_tls, "skip_means2d", False) and not torch.is_grad_enabled()
+        # (inside Function.forward grad mode is always off, so the guard is the inputs' requires_grad, not grad mode)
+        want_grad = any(t is not None and t.requires_grad for t in (means, quats, scales, opacities, colors, viewmats,
+                                                                    covars))
+        skip_m2d = getattr(_tls, "skip_means2d", False) and not want_grad
         means2d = None if skip_m2d else torch.empty(C, N, 2, device=dev, dtype=torch.float32)
         # rows with radii == 0 are never written nor read (as gsplat's torch.empty projection outputs)
         splats = torch.empty(C, N, B.GS_REC, device=dev, dtype=torch.float32)
         # split SH backward: the forward also leaves each camera's visibility words; their scanned populations give
         # every visible pair its row in the packed colour-gradient message of the backward
         exchange = current_exchange()
-        want_grad = any(t is not None and t.requires_grad for t in (means, quats, scales, opacities, colors, viewmats))
         split = (params.color_mode == B.GS_COLOR_SH and covars is None and N > 0 and want_grad
                  and (SPLIT_SH_BACKWARD or (exchange is not None and exchange.packs_colours)))
         vis_words = vis_counts = None
@@ -291,7 +293,10 @@ class _ProjectSplats(torch.autograd.Function):
         cap, lay_cams = int(host[0]), int(host[1])
         assert lay_cams >= C and cap >= 0, (lay_cams, C, cap)
         lay = colour_message_layout(lay_cams, N, cap)
-        msg = torch.empty(lay["total"], device=dev, dtype=torch.uint8)
+        # (tests set POISON_MESSAGES: the sections of absent cameras and the rows beyond the visible pairs are never
+        # written by the geometry kernel and must never be read by the SH kernel)
+        msg = (torch.full((lay["total"],), 0xEE, device=dev, dtype=torch.uint8) if POISON_MESSAGES
+               else torch.empty(lay["total"], device=dev, dtype=torch.uint8))
         with B.device_guard(dev), B.timed("gs_projection_bwd", dev):
             B.check(B.lib().gs_projection_bwd_split(
                 ctypes.byref(p), B.ptr(means), B.ptr(quats), B.ptr(scales), B.ptr(opacities), B.ptr(viewmats),
@@ -448,37 +453,47 @@ class FrontSort:
 _ISECT_LABELS = ("gs_isect_bin_count", "gs_isect_bin_offsets", "gs_raster_tile_order", "gs_isect_bin_scatter",
                  "gs_isect_tile_sort")
 _RASTER_FWD_LABELS = ("gs_rasterize_fwd", "gs_rasterize_fwd_redo", "gs_isect_tile_sort_redo")
-_host_scalars = {}
-_post_slots = {}
+_host_scalars = threading.local()
+_post_slots = threading.local()
+POISON_MESSAGES = False  # tests only: fill the colour-gradient message with 0xEE before the kernel writes it
 POSTED_RESULTS = True  # n_isects and the size classes are posted into a polled host slot by the kernels themselves
 
 
 def _host_scalar() -> Tensor:
     """A pinned int64 the composite prepare call writes n_isects into (one per thread: the call synchronises before it
     returns, so the value is consumed before the next call can overwrite it)."""
-    import threading
-
-    key = threading.get_ident()
-    t = _host_scalars.get(key)
+    t = getattr(_host_scalars, "t", None)
     if t is None:
-        t = _host_scalars[key] = torch.zeros(3, dtype=torch.int64).pin_memory()  # n_isects | 3 x int32 size classes
+        t = _host_scalars.t = torch.zeros(3, dtype=torch.int64).pin_memory()  # n_isects | 3 x int32 size classes
     return t
 
 
-def _post_slot():
-    """(address, int64 view, int32 view) of this thread's host slot for posted results (include/gsplat_mi355x.h,
-    "posted results"): int64 n_isects | int32[3] size classes.  One per (thread, device context), kept for the life of
-    the process."""
-    import threading
+class _PostSlot:
+    """One host slot for posted results (include/gsplat_mi355x.h, "posted results"): int64 n_isects | int32[3] size
+    classes, in portable pinned memory (one address for every device).  Owned by the thread that made it
+    (threading.local) and freed with it; a wait on the slot is synchronous, so a thread needs exactly one."""
 
-    key = threading.get_ident()
-    slot = _post_slots.get(key)
-    if slot is None:
+    def __init__(self):
         p = ctypes.c_void_p()
         B.check(B.lib().gs_host_post_alloc(ctypes.byref(p), 64), "gs_host_post_alloc")
-        slot = _post_slots[key] = (p.value, (ctypes.c_int64 * 1).from_address(p.value),
-                                   (ctypes.c_int32 * 3).from_address(p.value + 8))
-    return slot
+        self.addr = p.value
+        self.views = (p.value, (ctypes.c_int64 * 1).from_address(p.value), (ctypes.c_int32 * 3).from_address(p.value + 8))
+
+    def __del__(self):
+        try:
+            if self.addr:
+                B.lib().gs_host_post_free(ctypes.c_void_p(self.addr))
+                self.addr = None
+        except Exception:  # interpreter shutdown: the process's pinned memory goes with it
+            pass
+
+
+def _post_slot():
+    """(address, int64 view, int32 view) of the calling thread's host slot."""
+    slot = getattr(_post_slots, "slot", None)
+    if slot is None:
+        slot = _post_slots.slot = _PostSlot()
+    return slot.views
 
 
 SLICES_TOTAL = 512        # count-pass workgroups over all cameras (row slices x cameras)

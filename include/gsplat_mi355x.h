@@ -231,7 +231,10 @@ int gs_radix_sort_pairs_u64_u32_ex(int64_t n_max, const int64_t* n_dev, int32_t 
  * (GS_RADIX_SORT_STATIC_MAX_N / 4096 * 2 KiB + 2 KiB = 8 MiB + 2 KiB per GPU the library runs on, held until the process
  * ends); n > GS_RADIX_SORT_STATIC_MAX_N returns GS_ERR_WORKSPACE.  Same kernels, same result bit for bit as
  * gs_radix_sort_pairs_u64_u32_bits.  All calls on one GPU share that GPU's table: calls that overlap in time on one GPU
- * (different streams or threads) race -- serialise them. */
+ * (different streams or threads) race -- serialise them.  The stream's device must be the CURRENT device (else
+ * GS_ERR_INVALID_ARG: every GPU has its own copy of the table at its own address).  The first call on a device looks that
+ * address up (hipGetSymbolAddress, may load the code object): make one call outside any stream capture per device first
+ * -- n = 0 is enough -- before calling it on a capturing stream. */
 #define GS_RADIX_SORT_STATIC_MAX_N (1 << 24)
 int gs_radix_sort_pairs_u64_u32_static(int64_t n, int32_t begin_bit, int32_t end_bit,
                                        uint64_t* keys_a, uint32_t* vals_a,

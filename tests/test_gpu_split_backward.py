@@ -123,6 +123,10 @@ def _rank_main(rank, world, port, mode, q):
     wc = torch.randn(C, H, W, 4, generator=gen)[sl].to(dev)
     wa = torch.randn(C, H, W, 1, generator=gen)[sl].to(dev)
     ex = GradientExchange(mode=mode)
+    # unequal shards: the layout holds 3 cameras, rank 1's message fills 2 -- its third camera's sections and every row
+    # beyond its visible pairs stay unwritten; poison them (0xEE bytes are NaN-free garbage that would show in v_sh)
+    import gsplat.cuda._wrapper as Wm
+    Wm.POISON_MESSAGES = True
     with ex:
         rc, ra, meta = rasterization(p["means"], p["quats"], p["scales"], p["opacities"], p["colors"], vm[sl].to(dev),
                                      Ks[sl].to(dev), W, H, near_plane=0.1, sh_degree=3, packed=False,

@@ -69,3 +69,28 @@ def test_static_scratch_sort_rejects_oversize_and_bad_args(gpu_device):
     assert lib.gs_radix_sort_pairs_u64_u32_static(8, 0, 70, B.ptr(one), B.ptr(one), B.ptr(one), B.ptr(one),
                                                   ctypes.byref(in_b), st) == -1
     assert lib.gs_radix_sort_pairs_u64_u32_static(0, 0, 46, None, None, None, None, ctypes.byref(in_b), st) == 0
+
+
+def test_static_scratch_sort_on_a_side_stream_under_device_guard(gpu_device):
+    """The scratch copy is chosen for the stream's device, which must be the current one (header): a non-default stream
+    of the device under `device_guard` sorts like the default stream."""
+    from gsplat import _backend as B
+
+    lib = B.lib()
+    rng = np.random.default_rng(11)
+    n = 300_007
+    keys = rng.integers(0, (1 << 45) - 1, size=n, dtype=np.int64)
+    vals = np.arange(n, dtype=np.int32)
+    side = torch.cuda.Stream(gpu_device)
+    ka, va = torch.from_numpy(keys).to(gpu_device), torch.from_numpy(vals).to(gpu_device)
+    kb, vb = torch.empty_like(ka), torch.empty_like(va)
+    in_b = ctypes.c_int32(-1)
+    side.wait_stream(torch.cuda.current_stream(gpu_device))
+    with B.device_guard(gpu_device):
+        rc = lib.gs_radix_sort_pairs_u64_u32_static(n, 0, 46, B.ptr(ka), B.ptr(va), B.ptr(kb), B.ptr(vb),
+                                                    ctypes.byref(in_b), side.cuda_stream)
+    assert rc == 0
+    side.synchronize()
+    k, v = (kb, vb) if in_b.value else (ka, va)
+    order = np.argsort(keys.astype(np.uint64), kind="stable")
+    assert np.array_equal(v.cpu().numpy(), vals[order]) and np.array_equal(k.cpu().numpy(), keys[order])
