@@ -833,6 +833,7 @@ class _RasterizeSplats(torch.autograd.Function):
         launch_raster_fwd(splats, offsets, flatten_ids, order, fs, bg, (C, N, width, height, tile_size, channels, ed),
                           rc, ra, last_ids, work, None, final_T)
         _tls.front_sort = fs
+        _tls.last_tile_work = work  # (diagnostics: bench.py sums it into the list entries the backward walks)
         _tls.raster_state = (splats, offsets, isect_ids, flatten_ids, order, fs)  # handed to rasterization() for the lazy completion of meta["isect_ids"/"flatten_ids"]
         order_bwd = None
         if work is not None:

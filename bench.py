@@ -66,6 +66,21 @@ def algorithmic_bytes(N, C, H, W, K, D, V, I, absgrad=True, aa=True):
     return b
 
 
+def processed_bytes(N, C, H, W, K, D, V, Ic, Wk, absgrad=True):
+    """The same per-unit figures with the units the kernels actually process in place of gsplat's I: Ic = entries of the
+    culled tile lists the scatter / sort / rasterizers run on (pairs whose splat cannot reach alpha 1/255 on the tile
+    are never emitted), Wk = list entries the compositor walks before every pixel of the tile has stopped (the forward
+    reads that many records front to back, the backward the same ones back to front).  The sort moves 8-B (depth, id)
+    pairs in and 4-B ids out: the 8-B keys are only materialised when `meta` is asked for gsplat's arrays."""
+    P = C * H * W
+    b = {}
+    b["gs_isect_bin_scatter"] = Ic * 8 + V * 24          # pair stores + the visible-list entries and tile masks read
+    b["gs_isect_tile_sort"] = Ic * (8 + 4)
+    b["gs_rasterize_fwd"] = Wk * (28 + 4 * D) + P * (4 * D + 8 + 4)   # (+4: the exact final transmittance)
+    b["gs_rasterize_bwd"] = Wk * (28 + 4 * D) + P * (4 * D + 12 + 4) + V * (4 * D + 12 + 8 + 4 + (8 if absgrad else 0))
+    return b
+
+
 def measured_traffic(kernel, N, C, H, W):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.py writes the
     file; FETCH_SIZE and WRITE_SIZE need separate passes, so they cannot be collected inside this run)."""
@@ -92,8 +107,17 @@ def measured_issue(kernel):
         return None
     if not k or "valu_issue_frac" not in k:
         return None
-    return {"bound": "valu_issue", "frac": k["valu_issue_frac"], "valu_active_per_simd": k["valu_active"],
+    # three readings of "how close to the vector-ALU issue limit" (profiles/pmc_issue.py states each formula):
+    #   busy_counter      4 * SQ_ACTIVE_INST_VALU / (kernel cycles * 1024 SIMDs): a busy counter, reads > 1 when two
+    #                     waves' instructions overlap in the pipe -- says "saturated", not how far from a roofline
+    #   frac_at_2_cycles  SQ_INSTS_VALU * 2 cycles / (kernel cycles * 1024): the guide's v_fma_f32 rate, the hard ceiling
+    #   frac_mix_weighted SQ_INSTS_VALU weighted by this part's measured per-class issue costs
+    #                     (profiles/r02_valu_ubench.txt) over the kernel's static instruction mix
+    return {"bound": "valu_issue", "frac": k.get("valu_issue_frac_mix", k["valu_issue_frac"]),
+            "busy_counter": k["valu_active"], "frac_at_2_cycles": k.get("valu_issue_frac_2cyc"),
+            "frac_mix_weighted": k.get("valu_issue_frac_mix"), "mix": k.get("valu_mix"),
             "waves_per_simd": k.get("waves_per_simd"), "insts_valu": k.get("insts_valu"),
+            "kernel_cycles": k.get("kernel_cycles"), "vgprs": k.get("vgprs"),
             "lds_bank_conflict_rate": k.get("lds_bank_conflict_rate"), "atomic_GBps": k.get("atomic_GBps"),
             "atomic_frac_of_peak": k.get("atomic_frac_of_1300GBps"),
             "source": "profiles/issue.json (rocprofv3 --pmc SQ_ACTIVE_INST_VALU, SQ_BUSY_CYCLES, SQ_LDS_BANK_CONFLICT, "
@@ -429,7 +453,11 @@ def main():
     # gsplat's intersection count = the sum of the tile-box counts (what SURVEY.md 8(d)'s formulas are written in); the
     # culled lists the rasterizer runs on are shorter, and asking `meta` for flatten_ids would build the full ones
     I = int(meta["tiles_per_gauss"].sum().item())
-    del meta
+    lists = getattr(meta, "_lists", None)
+    Ic = int(lists[3].numel()) if lists is not None else I      # entries of the lists the rasterizer ran on
+    work = getattr(Wm._tls, "last_tile_work", None)
+    Wk = int(work.sum().item()) if work is not None else Ic     # ... and how many of them the compositor walks
+    del meta, lists, work
 
     def barrier():
         if world > 1:
@@ -470,6 +498,7 @@ def main():
         ms = dt / args.steps * 1e3
         value = world * C * H * W * args.steps / dt / 1e6
         bytes_ = algorithmic_bytes(N, C, H, W, K, D, V, I)
+        proc_ = processed_bytes(N, C, H, W, K, D, V, Ic, Wk)
         kern_ms = {k: round(v[1], 4) for k, v in kern_all.items()}
         kern_calls = {k: v[0] / 3 for k, v in kern_all.items()}
         roofline = None
@@ -479,6 +508,16 @@ def main():
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": measured_traffic(dom, N, C, H, W),
                         "algorithmic_bytes_per_launch": bytes_[dom], "avg_launch_ms": round(per_launch_ms, 4),
+                        # two clocks on the same kernel, both HIP events on its launch stream: `avg_launch_ms` is taken
+                        # inside the timed region (production schedule: only this kernel bracketed); the pre-pass
+                        # brackets EVERY entry point, which serialises the side stream's fill behind the forward and
+                        # leaves more dirty lines for this kernel to wait on.  rocprofv3's average
+                        # (profiles/*kernel_stats.csv) is of the pre-pass kind.  `frac` uses the first.
+                        "avg_launch_ms_prepass_all_bracketed": round(kern_all[dom][1], 4),
+                        "frac_prepass": round(bytes_[dom] / (kern_all[dom][1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                        "processed_bytes_per_launch": proc_.get(dom),
+                        "frac_processed": (round(proc_[dom] / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                                           if dom in proc_ else None),
                         "secondary": measured_issue(dom) if headline_shape else None}
         # the same figure for every stage that has algorithmic bytes (pre-pass launch averages; the sort chain and the
         # redo launches are folded into their stage's entry point)
@@ -491,6 +530,9 @@ def main():
                 gbs = nbytes / (ms_k * 1e-3) / 1e9
                 per_kernel[k] = {"ms": round(ms_k, 4), "algorithmic_bytes": nbytes, "GB/s": round(gbs, 1),
                                  "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+                if k in proc_:  # reference-formula bytes above; the bytes of the lists actually processed here
+                    per_kernel[k]["processed_bytes"] = proc_[k]
+                    per_kernel[k]["processed_GB/s"] = round(proc_[k] / (ms_k * 1e-3) / 1e9, 1)
         total_bytes = sum(bytes_.values())
         headline = headline_shape and args.mode == "train"
         workload = (("configs[1]: " if headline else "NOT the headline: ") +
@@ -510,6 +552,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "gaussians": N, "cams_per_gpu": C,
                        "width": W, "height": H, "visible_pairs_V": V, "n_isects_I": I,
+                       "tile_list_entries_culled": Ic, "tile_list_entries_walked": Wk,
                        "parallelism": (f"camera/frame DP x{world}, gradient exchange '{exchange.mode}' "
                                        f"({'gloo REHEARSAL, not a result' if args.rehearse_gloo else 'RCCL'}), "
                                        f"{exchange.bytes_sent // max(1, args.steps + args.warmup + 3 + (args.warmup == 0))} "

@@ -12,15 +12,32 @@ Units (/opt/skills/guides/MI355X_MICROARCH.md, "rocprofv3 PMC slots" / "Per-inst
   SQ_INSTS_VALU           wave-instructions
   SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE   extra LDS-array cycles / all LDS-array cycles
   TCC_EA0_ATOMIC_sum      64-B atomic requests leaving L2 for the memory side
-valu_active = 4 * SQ_ACTIVE_INST_VALU / (kernel cycles * 1024 SIMDs): the share of every SIMD's time with a vector
-instruction in execution.  Two waves' instructions overlap in the SIMD's pipeline, so a saturated SIMD reads slightly
-above 1; `valu_issue_frac` is that value clipped to 1."""
+Three readings of the vector-ALU issue roofline per kernel:
+  valu_active           = 4 * SQ_ACTIVE_INST_VALU / (kernel cycles * 1024 SIMDs): the share of every SIMD's time with a
+                          vector instruction in execution.  A BUSY counter: two waves' instructions overlap in the SIMD's
+                          pipeline, so a saturated SIMD reads above 1.  It says "saturated", not how far from a roofline
+                          (`valu_issue_frac` is that value clipped to 1, kept for older readers of the file).
+  valu_issue_frac_2cyc  = SQ_INSTS_VALU * 2 cycles / (kernel cycles * 1024): instructions at the guide's best rate (one
+                          wave64 v_fma_f32 per 2 SIMD cycles) -- the hard ceiling; the distance to 1 is instruction mix
+                          (compares, selects, transcendentals, lane swaps issue slower) plus idle issue slots.
+  valu_issue_frac_mix   = SQ_INSTS_VALU * mean issue cost of the kernel's static inner-loop instruction mix (ns per
+                          wave-instruction per SIMD, measured per class on this part: profiles/isa_mix.py,
+                          profiles/r02_valu_ubench.txt) / 1024 / average launch time: what is left to 1 is idle issue
+                          slots (tile tails, staging, waits); a value near 1 says only fewer or cheaper instructions
+                          make the kernel faster."""
 import csv
 import glob
 import json
 import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import isa_mix  # noqa: E402
+
+# label -> (source file, demangled template instance of the bench's configuration)
+ISA = {"gs_rasterize_bwd": ("rasterize", "rasterize_bwd_kernel<4, true>"),
+       "gs_rasterize_fwd": ("rasterize", "rasterize_fwd_kernel<4>")}
 
 SIMDS = 256 * 4
 KERNELS = {
@@ -76,6 +93,16 @@ def main():
             va = 4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (cyc * SIMDS)
             e["valu_active"] = round(va, 4)
             e["valu_issue_frac"] = round(min(va, 1.0), 4)
+            e["valu_issue_frac_2cyc"] = round(c.get("SQ_INSTS_VALU", 0.0) * 2.0 / (cyc * SIMDS), 4)
+            if label in ISA and ns:
+                try:
+                    mix = isa_mix.kernel_mix(*ISA[label])
+                    e["valu_mix"] = mix
+                    e["vgprs"] = mix["vgprs"]
+                    e["valu_issue_frac_mix"] = round(c.get("SQ_INSTS_VALU", 0.0) * mix["mean_issue_ns_per_wave_instruction"]
+                                                     / SIMDS / ns, 4)
+                except (SystemExit, Exception) as ex:  # (no hipcc where this runs: the two counter readings remain)
+                    e["valu_mix_error"] = str(ex)
             e["waves_per_simd"] = round(4.0 * c.get("SQ_WAVE_CYCLES", 0.0) / (cyc * SIMDS), 3)
         wc = c.get("SQ_WAVE_CYCLES", 0.0)
         if wc > 0:
