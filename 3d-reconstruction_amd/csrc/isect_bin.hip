@@ -383,8 +383,10 @@ template <bool CULL>
 __global__ __launch_bounds__(BIN_THREADS) void isect_region_scatter_kernel(
     int32_t tile_w, int32_t tile_h, int32_t T, int32_t n_slices, int32_t G, int32_t R, int32_t seg_cap,
     const uint4* __restrict__ vis_list, const int32_t* __restrict__ vis_cnt, const uint2* __restrict__ vis_mask,
-    const uint32_t* __restrict__ table, const int32_t* __restrict__ offsets, uint2* __restrict__ pairs) {
+    const uint32_t* __restrict__ table, const int32_t* __restrict__ offsets, uint2* __restrict__ pairs,
+    const int64_t* __restrict__ n_dev, int64_t pair_cap) {
   extern __shared__ uint32_t cur[];  // [band tiles]
+  if (n_dev && *n_dev > pair_cap) return;  // speculative capacity too small: the host redoes the call (gs_isect_bin_build_dev)
   const int c = blockIdx.y, g = blockIdx.x / R, r = blockIdx.x - g * R;
   const int tid = threadIdx.x;
   const int ty0 = (int)((int64_t)r * tile_h / R), ty1 = (int)((int64_t)(r + 1) * tile_h / R);
@@ -421,8 +423,10 @@ __global__ __launch_bounds__(BIN_THREADS) void isect_region_scatter_staged_kerne
     int32_t tile_w, int32_t tile_h, int32_t T, int32_t n_slices, int32_t G, int32_t R, int32_t seg_cap,
     int32_t nt_max, int32_t cap, const uint4* __restrict__ vis_list, const int32_t* __restrict__ vis_cnt,
     const uint2* __restrict__ vis_mask, const uint32_t* __restrict__ table, const int32_t* __restrict__ offsets,
-    const int32_t* __restrict__ tile_counts, uint2* __restrict__ pairs) {
+    const int32_t* __restrict__ tile_counts, uint2* __restrict__ pairs, const int64_t* __restrict__ n_dev,
+    int64_t pair_cap) {
   extern __shared__ uint32_t lds_raw[];
+  if (n_dev && *n_dev > pair_cap) return;  // (see isect_region_scatter_kernel)
   uint32_t* lcur = lds_raw;                                        // [nt_max] staging cursor per band tile
   uint32_t* gdelta = lds_raw + nt_max;                             // [nt_max] global position - staging position
   uint2* stage = reinterpret_cast<uint2*>(lds_raw + 2 * nt_max);  // [cap] {depth bits, row}
@@ -913,7 +917,15 @@ __global__ __launch_bounds__(WAVES * 64) void tile_sort_kernel(int32_t T, int32_
                                                                const int32_t* __restrict__ size_classes, uint2* pairs,
                                                                int64_t* isect_ids, int32_t* flatten_ids,
                                                                const int32_t* sel, int32_t sel_mode,
-                                                               int32_t* sorted_cnt, int32_t* contract_flag) {
+                                                               int32_t* sorted_cnt, int32_t* contract_flag,
+                                                               const int64_t* __restrict__ n_dev = nullptr) {
+  // n_dev: the intersection count in device memory; `n_isects` is then the CAPACITY the host sized the arrays for before
+  // it knew the count (gs_isect_bin_build_dev), and a count beyond it means nothing was scattered: do nothing
+  if (n_dev) {
+    const int64_t n_true = *n_dev;
+    if (n_true > n_isects) return;
+    n_isects = n_true;
+  }
   // sel != NULL restricts the launch to the tiles with sel[tile] < 0 (sel_mode 0: segments the front sort deferred)
   // or sel[tile] != 0 (sel_mode 1: tiles the rasterizer flagged); sorted_cnt[tile] = n marks a segment fully sorted
   constexpr int THREADS = WAVES * 64;
@@ -1252,11 +1264,11 @@ extern "C" int gs_isect_bin_scatter(int32_t C, int32_t N, int32_t tile_w, int32_
   return GS_OK;
 }
 
-extern "C" int gs_isect_bin_scatter_regions(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, int32_t n_slices,
-                                            int32_t slices_per_group, int32_t n_regions, const uint64_t* vis_list,
-                                            const int32_t* vis_counts, const uint64_t* vis_masks,
-                                            const uint32_t* table, const int32_t* isect_offsets,
-                                            const int32_t* tile_counts, uint64_t* pairs, void* stream) {
+static int scatter_regions_impl(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, int32_t n_slices,
+                                int32_t slices_per_group, int32_t n_regions, const uint64_t* vis_list,
+                                const int32_t* vis_counts, const uint64_t* vis_masks, const uint32_t* table,
+                                const int32_t* isect_offsets, const int32_t* tile_counts, uint64_t* pairs,
+                                const int64_t* n_dev, int64_t pair_cap, void* stream) {
   int st = bin_check(C, N, tile_w, tile_h, n_slices);
   if (st != GS_OK) return st;
   if (slices_per_group < 1 || n_regions < 1 || n_regions > 65535) return GS_ERR_INVALID_ARG;
@@ -1285,13 +1297,13 @@ extern "C" int gs_isect_bin_scatter_regions(int32_t C, int32_t N, int32_t tile_w
                          bin_slice_rows(N, n_slices), (int32_t)nt_max, (int32_t)cap,
                          reinterpret_cast<const uint4*>(vis_list), vis_counts,
                          reinterpret_cast<const uint2*>(vis_masks), table, isect_offsets, tile_counts,
-                         reinterpret_cast<uint2*>(pairs));
+                         reinterpret_cast<uint2*>(pairs), n_dev, pair_cap);
     else
       hipLaunchKernelGGL(gs::isect_region_scatter_staged_kernel<false>, grid, dim3(gs::BIN_THREADS), lds_staged,
                          (hipStream_t)stream, tile_w, tile_h, T, n_slices, slices_per_group, n_regions,
                          bin_slice_rows(N, n_slices), (int32_t)nt_max, (int32_t)cap,
                          reinterpret_cast<const uint4*>(vis_list), vis_counts, (const uint2*)nullptr, table,
-                         isect_offsets, tile_counts, reinterpret_cast<uint2*>(pairs));
+                         isect_offsets, tile_counts, reinterpret_cast<uint2*>(pairs), n_dev, pair_cap);
     GS_CHECK_LAUNCH();
     return GS_OK;
   }
@@ -1299,14 +1311,23 @@ extern "C" int gs_isect_bin_scatter_regions(int32_t C, int32_t N, int32_t tile_w
     hipLaunchKernelGGL(gs::isect_region_scatter_kernel<true>, grid, dim3(gs::BIN_THREADS), lds, (hipStream_t)stream,
                        tile_w, tile_h, T, n_slices, slices_per_group, n_regions, bin_slice_rows(N, n_slices),
                        reinterpret_cast<const uint4*>(vis_list), vis_counts, reinterpret_cast<const uint2*>(vis_masks),
-                       table, isect_offsets, reinterpret_cast<uint2*>(pairs));
+                       table, isect_offsets, reinterpret_cast<uint2*>(pairs), n_dev, pair_cap);
   else
     hipLaunchKernelGGL(gs::isect_region_scatter_kernel<false>, grid, dim3(gs::BIN_THREADS), lds, (hipStream_t)stream,
                        tile_w, tile_h, T, n_slices, slices_per_group, n_regions, bin_slice_rows(N, n_slices),
                        reinterpret_cast<const uint4*>(vis_list), vis_counts, (const uint2*)nullptr, table,
-                       isect_offsets, reinterpret_cast<uint2*>(pairs));
+                       isect_offsets, reinterpret_cast<uint2*>(pairs), n_dev, pair_cap);
   GS_CHECK_LAUNCH();
   return GS_OK;
+}
+
+extern "C" int gs_isect_bin_scatter_regions(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, int32_t n_slices,
+                                            int32_t slices_per_group, int32_t n_regions, const uint64_t* vis_list,
+                                            const int32_t* vis_counts, const uint64_t* vis_masks,
+                                            const uint32_t* table, const int32_t* isect_offsets,
+                                            const int32_t* tile_counts, uint64_t* pairs, void* stream) {
+  return scatter_regions_impl(C, N, tile_w, tile_h, n_slices, slices_per_group, n_regions, vis_list, vis_counts,
+                              vis_masks, table, isect_offsets, tile_counts, pairs, nullptr, 0, stream);
 }
 
 // `sch` (host copy of size_classes, or NULL): lets the host skip the launches of size classes that hold no tile -- on the
@@ -1329,14 +1350,16 @@ static inline bool ts_ids_optional(const int32_t* tile_order, const int32_t* siz
 
 static int tile_sort_impl(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets, int64_t n_isects,
                           const int32_t* tile_order, const int32_t* size_classes, uint64_t* pairs, int64_t* isect_ids,
-                          int32_t* flatten_ids, const int32_t* sch, void* stream) {
+                          int32_t* flatten_ids, const int32_t* sch, void* stream, const int64_t* n_dev = nullptr) {
   if (C < 1 || tile_w < 1 || tile_h < 1 || n_isects < 0) return GS_ERR_INVALID_ARG;
   if (gs_contract_take()) return GS_ERR_CONTRACT;
   if (n_isects == 0) return GS_OK;
   if (n_isects >= ((int64_t)1 << 31)) return GS_ERR_UNSUPPORTED;
   if (!isect_offsets || !pairs || !flatten_ids) return GS_ERR_INVALID_ARG;
   const int T = tile_w * tile_h;
-  if (!isect_ids && !ts_ids_optional(tile_order, size_classes, sch, (int64_t)C * T)) return GS_ERR_INVALID_ARG;
+  // (n_dev: the host does not know the size classes yet; a list beyond the longest class's LDS buffer without the
+  // isect_ids scratch raises the contract flag, which the caller of gs_isect_bin_build_dev checks for)
+  if (!isect_ids && !n_dev && !ts_ids_optional(tile_order, size_classes, sch, (int64_t)C * T)) return GS_ERR_INVALID_ARG;
   const int tile_n_bits = gs::bin_ilog2_floor(T) + 1;
   const int cam_n_bits = gs::bin_ilog2_floor(C) + 1;
   if (32 + tile_n_bits + cam_n_bits > 64) return GS_ERR_UNSUPPORTED;
@@ -1344,7 +1367,7 @@ static int tile_sort_impl(int32_t C, int32_t tile_w, int32_t tile_h, const int32
   hipStream_t s = (hipStream_t)stream;
   uint2* pr = reinterpret_cast<uint2*>(pairs);
   int32_t* cf = gs_contract_flag_device();
-#define GS_TS_ARGS T, tile_n_bits, n_tiles, isect_offsets, n_isects, tile_order, size_classes, pr, isect_ids, flatten_ids, (const int32_t*)nullptr, 0, (int32_t*)nullptr, cf
+#define GS_TS_ARGS T, tile_n_bits, n_tiles, isect_offsets, n_isects, tile_order, size_classes, pr, isect_ids, flatten_ids, (const int32_t*)nullptr, 0, (int32_t*)nullptr, cf, n_dev
   if (tile_order && size_classes) {
     // longest lists first; grids are persistent and sized to the LDS-limited residency of each class; the short
     // classes run 4 / 2 waves per segment (one wave each left 8 waves per CU: 0.136 -> 0.110 ms for the chain)
@@ -1369,6 +1392,26 @@ extern "C" int gs_isect_tile_sort(int32_t C, int32_t tile_w, int32_t tile_h, con
                                   int64_t* isect_ids, int32_t* flatten_ids, void* stream) {
   return tile_sort_impl(C, tile_w, tile_h, isect_offsets, n_isects, tile_order, size_classes, pairs, isect_ids,
                         flatten_ids, nullptr, stream);
+}
+
+// gs_isect_bin_scatter_regions + gs_isect_tile_sort for a host that has NOT read n_isects yet (include/gsplat_mi355x.h,
+// "device-side n_isects"): `capacity` sizes pairs / flatten_ids (/ isect_ids), the count is read from *n_isects_dev by
+// the kernels; all four size classes are launched (the host does not know which ones hold tiles) and every list is sorted
+// whole.  A count beyond the capacity leaves the arrays untouched.
+extern "C" int gs_isect_bin_build_dev(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, int32_t n_slices,
+                                      int32_t slices_per_group, int32_t n_regions, const uint64_t* vis_list,
+                                      const int32_t* vis_counts, const uint64_t* vis_masks, const uint32_t* table,
+                                      const int32_t* isect_offsets, int64_t capacity, const int64_t* n_isects_dev,
+                                      const int32_t* tile_order, const int32_t* size_classes, uint64_t* pairs,
+                                      int64_t* isect_ids, int32_t* flatten_ids, const int32_t* tile_counts,
+                                      void* stream) {
+  if (!n_isects_dev || capacity < 1 || !tile_order || !size_classes) return GS_ERR_INVALID_ARG;
+  int st = scatter_regions_impl(C, N, tile_w, tile_h, n_slices, slices_per_group, n_regions, vis_list, vis_counts,
+                                vis_masks, table, isect_offsets, tile_counts, pairs, n_isects_dev, capacity, stream);
+  if (st != GS_OK) return st;
+  if (N == 0) return GS_OK;
+  return tile_sort_impl(C, tile_w, tile_h, isect_offsets, capacity, tile_order, size_classes, pairs, isect_ids,
+                        flatten_ids, nullptr, stream, n_isects_dev);
 }
 
 extern "C" int gs_isect_tile_sort_ex(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets,

@@ -120,8 +120,16 @@ __global__ __launch_bounds__(64) void rasterize_fwd_kernel(
     float* __restrict__ out_c, float* __restrict__ out_a, int32_t* __restrict__ last_ids,
     const int32_t* __restrict__ tile_order, int32_t* __restrict__ tile_work,
     const int32_t* __restrict__ sorted_cnt, int32_t* __restrict__ redo_flags, int redo_pass,
-    const float* __restrict__ opac_override, int n_per_cam, float* __restrict__ out_T) {
+    const float* __restrict__ opac_override, int n_per_cam, float* __restrict__ out_T,
+    const int64_t* __restrict__ n_dev) {
   __shared__ float4 sg[Q_SLOTS * 3];
+  // n_dev: the intersection count in device memory, `n_isects` the capacity the lists were allocated with before the
+  // host knew the count (gs_rasterize_fwd_dev); a count beyond it means the lists were never built: write nothing
+  if (n_dev) {
+    const int64_t n_true = *n_dev;
+    if (n_true > n_isects) return;
+    n_isects = n_true;
+  }
   __shared__ unsigned short qidx[4 * Q_STRIDE];
   const unsigned n_tiles = (unsigned)(C * TW * TH);
   unsigned tile;
@@ -603,16 +611,16 @@ static int raster_check(int32_t C, int32_t width, int32_t height, int32_t tile_s
   return GS_OK;
 }
 
-#define GS_RF_ARGS C, width, height, TW, TH, splats, isect_offsets, flatten_ids, n_isects, backgrounds, ed_last_channel, render_colors, render_alphas, last_ids, tile_order, tile_work, sorted_counts, redo_flags, redo_pass, opacity_override, n_per_camera, final_T
+#define GS_RF_ARGS C, width, height, TW, TH, splats, isect_offsets, flatten_ids, n_isects, backgrounds, ed_last_channel, render_colors, render_alphas, last_ids, tile_order, tile_work, sorted_counts, redo_flags, redo_pass, opacity_override, n_per_camera, final_T, n_dev
 #define GS_RF_LAUNCH(CHN) hipLaunchKernelGGL((gs::rasterize_fwd_kernel<CHN>), grid, block, 0, s, GS_RF_ARGS)
 
-extern "C" int gs_rasterize_fwd(int32_t C, int32_t width, int32_t height, int32_t tile_size, int32_t channels,
-                                const float* splats, const int32_t* isect_offsets, const int32_t* flatten_ids,
-                                int64_t n_isects, const float* backgrounds, int32_t ed_last_channel,
-                                float* render_colors, float* render_alphas, int32_t* last_ids,
-                                const int32_t* tile_order, int32_t* tile_work, const int32_t* sorted_counts,
-                                int32_t* redo_flags, int32_t redo_pass, const float* opacity_override,
-                                int32_t n_per_camera, float* final_T, void* stream) {
+static int rasterize_fwd_impl(int32_t C, int32_t width, int32_t height, int32_t tile_size, int32_t channels,
+                              const float* splats, const int32_t* isect_offsets, const int32_t* flatten_ids,
+                              int64_t n_isects, const float* backgrounds, int32_t ed_last_channel,
+                              float* render_colors, float* render_alphas, int32_t* last_ids,
+                              const int32_t* tile_order, int32_t* tile_work, const int32_t* sorted_counts,
+                              int32_t* redo_flags, int32_t redo_pass, const float* opacity_override,
+                              int32_t n_per_camera, float* final_T, const int64_t* n_dev, void* stream) {
   int st = raster_check(C, width, height, tile_size, channels, n_isects);
   if (st != GS_OK) return st;
   if (!isect_offsets || !render_colors || !render_alphas || !last_ids) return GS_ERR_INVALID_ARG;
@@ -632,6 +640,34 @@ extern "C" int gs_rasterize_fwd(int32_t C, int32_t width, int32_t height, int32_
   GS_CHECK_LAUNCH();
   return GS_OK;
 }
+
+extern "C" int gs_rasterize_fwd(int32_t C, int32_t width, int32_t height, int32_t tile_size, int32_t channels,
+                                const float* splats, const int32_t* isect_offsets, const int32_t* flatten_ids,
+                                int64_t n_isects, const float* backgrounds, int32_t ed_last_channel,
+                                float* render_colors, float* render_alphas, int32_t* last_ids,
+                                const int32_t* tile_order, int32_t* tile_work, const int32_t* sorted_counts,
+                                int32_t* redo_flags, int32_t redo_pass, const float* opacity_override,
+                                int32_t n_per_camera, float* final_T, void* stream) {
+  return rasterize_fwd_impl(C, width, height, tile_size, channels, splats, isect_offsets, flatten_ids, n_isects,
+                            backgrounds, ed_last_channel, render_colors, render_alphas, last_ids, tile_order, tile_work,
+                            sorted_counts, redo_flags, redo_pass, opacity_override, n_per_camera, final_T, nullptr,
+                            stream);
+}
+
+// The same launch for a host that has not read the intersection count yet (include/gsplat_mi355x.h, "device-side
+// n_isects"): `capacity` sizes flatten_ids, the count is read from *n_isects_dev by the kernel.
+extern "C" int gs_rasterize_fwd_dev(int32_t C, int32_t width, int32_t height, int32_t tile_size, int32_t channels,
+                                    const float* splats, const int32_t* isect_offsets, const int32_t* flatten_ids,
+                                    int64_t capacity, const int64_t* n_isects_dev, const float* backgrounds,
+                                    int32_t ed_last_channel, float* render_colors, float* render_alphas,
+                                    int32_t* last_ids, const int32_t* tile_order, int32_t* tile_work,
+                                    const float* opacity_override, int32_t n_per_camera, float* final_T, void* stream) {
+  if (!n_isects_dev || capacity < 1 || !flatten_ids || !splats) return GS_ERR_INVALID_ARG;
+  return rasterize_fwd_impl(C, width, height, tile_size, channels, splats, isect_offsets, flatten_ids, capacity,
+                            backgrounds, ed_last_channel, render_colors, render_alphas, last_ids, tile_order, tile_work,
+                            nullptr, nullptr, 0, opacity_override, n_per_camera, final_T, n_isects_dev, stream);
+}
+
 
 #define GS_RB_ARGS C, width, height, TW, TH, splats, isect_offsets, flatten_ids, n_isects, backgrounds, ed_last_channel, render_colors, render_alphas, last_ids, v_render_colors, v_render_alphas, v_splats, tile_order, final_T
 #define GS_RB_LAUNCH(CHN)                                                                              \

@@ -15,6 +15,7 @@ import torch
 
 GS_REC = 16
 GS_COLOR_NONE, GS_COLOR_N, GS_COLOR_CN, GS_COLOR_SH = 0, 1, 2, 3
+GS_ERR_CONTRACT = -5  # include/gsplat_mi355x.h
 
 _LIB_NAME = "libgsplat_mi355x.so"
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "lib", _LIB_NAME)
@@ -72,6 +73,9 @@ _SIGNATURES = {
     "gs_host_post_alloc": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), c_int64]),
     "gs_host_post_free": (ctypes.c_int, [_P]),
     "gs_contract_status": (ctypes.c_int, [c_int32]),
+    "gs_isect_bin_build_dev": (ctypes.c_int, [c_int32] * 7 + [_P] * 5 + [c_int64] + [_P] * 8),
+    "gs_rasterize_fwd_dev": (ctypes.c_int, [c_int32] * 5 + [_P, _P, _P, c_int64, _P, _P, c_int32] + [_P] * 6 +
+                             [c_int32, _P, _P]),
     "gs_host_post_wait": (ctypes.c_int, [_P, _P, c_int32, _P]),
     "gs_visibility_prefix": (ctypes.c_int, [c_int32, c_int32, _P, _P, _P, _P, c_int64, _P]),
     "gs_isect_bin_build": (ctypes.c_int, [c_int32] * 7 + [_P] * 5 + [c_int64, _P, _P, c_int32, _P, _P, _P, _P, _P, _P]),

@@ -522,8 +522,60 @@ CULL_LISTS = True
 SIDE_STREAM_MIN_BYTES = 32 << 20
 
 
+# Speculative list sizes (include/gsplat_mi355x.h, "device-side n_isects"): rasterization() sizes the pair / id arrays
+# from the LAST call of the same shape (x SPEC_MARGIN) and issues scatter, sort and the forward rasterizer without waiting
+# for this call's count; the posted count is looked at once everything is queued, and a call that does not fit -- or
+# that has a tile list the speculative launches could not sort -- is redone through the exact-size path.  Same bits
+# either way.  Only taken when the previous call of the shape had no tile list above 2048 entries (those shapes are
+# GPU-bound and want the front-first sort, whose launches depend on the host knowing the size classes).
+SPECULATE_SIZES = True
+SPEC_MARGIN = 1.25
+_spec_tls = threading.local()
+
+
+def _spec_table() -> dict:
+    t = getattr(_spec_tls, "table", None)
+    if t is None:
+        t = _spec_tls.table = {}
+    return t
+
+
+class SpecLists:
+    """Tile lists built with a speculative capacity (gs_isect_bin_build_dev).  `resolve()` -- call it after the launches
+    that read the lists have been queued -- waits for the posted count (already there) and says whether the speculation
+    held; if not, `redo()` builds the lists again through the exact-size path."""
+
+    def __init__(self, capacity, total, isect_ids, flatten_ids, offsets, order, wait_posted, build_exact, key):
+        self.capacity, self.total = capacity, total
+        self.isect_ids, self.flatten_ids, self.offsets, self.order = isect_ids, flatten_ids, offsets, order
+        self._wait, self._build, self._key = wait_posted, build_exact, key
+        self.n_isects = self.classes = None
+
+    def resolve(self) -> bool:
+        self.n_isects, self.classes = self._wait()
+        _spec_table()[self._key] = (self.n_isects, tuple(self.classes))
+        ok = 0 < self.n_isects <= self.capacity and (self.classes[0] == 0 or self.isect_ids is not None)
+        if ok:
+            n = self.n_isects
+            self.flatten_ids = self.flatten_ids[:n]
+            self.isect_ids = self.isect_ids[:n] if self.isect_ids is not None else None
+        return ok
+
+    def redo(self):
+        dev = self.flatten_ids.device
+        if self.classes[0] > 0 and self.isect_ids is None:
+            # a speculative sort launch may have met a list beyond its buffer and raised the contract flag: let it
+            # finish, then clear the flag (this call's lists are rebuilt below; nobody else's launches are in flight
+            # on this stream)
+            with B.device_guard(dev):
+                B.check(B.lib().gs_stream_synchronize(B.stream_handle(dev)), "gs_stream_synchronize")
+                B.lib().gs_contract_status(1)
+        return self._build(self.n_isects, self.classes)
+
+
 def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int, tile_height: int,
-                       front: bool = False, cull_tile_size: int = 0, while_counting=None, want_ids: bool = True):
+                       front: bool = False, cull_tile_size: int = 0, while_counting=None, want_ids: bool = True,
+                       spec_key=None):
     """isect_tiles + sort + isect_offset_encode in one binned pipeline (include/gsplat_mi355x.h, "binned isect_tiles").
     Returns (isect_ids int64 [I] sorted, flatten_ids int32 [I], isect_offsets int32 [C,TH,TW], tile_order, front_sort),
     the first three bit-identical to `isect_tiles_from_splats(sort=True)` + `isect_offset_encode`; tile_order is the
@@ -535,7 +587,9 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
     while_counting: a callable run after the count / offsets launches are queued and before the host waits for
     n_isects -- host work (allocations, independent launches) placed there hides behind the GPU's first stage.
     want_ids=False: a caller that only rasterizes; isect_ids is then None unless a list is longer than 2048 entries
-    (the longest sort class borrows the array as scratch)."""
+    (the longest sort class borrows the array as scratch).
+    spec_key (hashable, or None): the caller can take speculatively sized lists -- the return value is then a
+    `SpecLists` instead of the 5-tuple whenever the last call with this key allows it (SPECULATE_SIZES above)."""
     dev = B.require_gpu(splats, tiles_per_gauss)
     assert not cull_tile_size or REGION_SCATTER, "culled lists need the region scatter"
     C, N = tiles_per_gauss.shape
@@ -568,10 +622,69 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
     want_order = C * T <= 131072
     use_front = front and want_order
     fused = FUSED_LAUNCHES and REGION_SCATTER and not any(B.profiling_active(k) for k in _ISECT_LABELS)
-    order = n_long = redo_flags = sc_host = None
+    order = n_long = redo_flags = None
     if want_order:
         order = torch.empty(C * T, device=dev, dtype=torch.int32)
         n_long = torch.empty(3, device=dev, dtype=torch.int32)  # size classes of the order
+    def _build_lists(n_isects, classes):
+        """Everything behind the host's read of n_isects / the size classes: arrays of the exact size, scatter, sort."""
+        uf, sc, rf = use_front, None, None
+        if want_order:
+            # host copy of the tile order's size classes: launches for classes that hold no tile are skipped, and
+            # without a tile above 2048 entries there is no front to sort first
+            sc = (ctypes.c_int32 * 3)(*classes)
+            if sc[FRONT_FROM_CLASS] == 0:
+                uf = False
+        if uf and fused:  # (cleared here, once it is known that a front will be sorted, not by the prepare call)
+            rf = torch.zeros(C * T + 1, device=dev, dtype=torch.int32)
+        need_ids = want_ids or uf or sc is None or sc[0] > 0 or n_isects == 0
+        isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64) if need_ids else None
+        flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
+        if n_isects == 0:
+            return isect_ids, flatten_ids, offsets, None, None
+        pairs = torch.empty(n_isects, device=dev, dtype=torch.int64)
+        if fused:
+            with B.device_guard(dev):
+                B.check(lib.gs_isect_bin_build(C, N, tile_width, tile_height, n_slices, group, regions, B.ptr(vis_list),
+                                               B.ptr(vis_cnt), B.ptr(vis_masks), B.ptr(table), B.ptr(offsets), n_isects,
+                                               B.ptr(order), B.ptr(n_long), FRONT_K_TARGET if uf else 0,
+                                               B.ptr(pairs), B.ptr(isect_ids), B.ptr(flatten_ids),
+                                               B.ptr(counts) if (STAGED_SCATTER or uf) else None,
+                                               ctypes.addressof(sc) if sc is not None else None, st),
+                        "gs_isect_bin_build")
+            if uf:
+                fs = FrontSort((C, tile_width, tile_height), offsets, order, n_long, pairs, isect_ids, flatten_ids, counts,
+                               rf)
+                fs.size_classes_host = sc
+                return isect_ids, flatten_ids, offsets, order, fs
+            return isect_ids, flatten_ids, offsets, order, None
+        with B.device_guard(dev), B.timed("gs_isect_bin_scatter", dev):
+            if vis_list is not None:
+                B.check(lib.gs_isect_bin_scatter_regions(C, N, tile_width, tile_height, n_slices, group, regions,
+                                                         B.ptr(vis_list), B.ptr(vis_cnt), B.ptr(vis_masks), B.ptr(table),
+                                                         B.ptr(offsets), B.ptr(counts) if STAGED_SCATTER else None,
+                                                         B.ptr(pairs), st), "gs_isect_bin_scatter_regions")
+            else:
+                B.check(lib.gs_isect_bin_scatter(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
+                                                 n_slices, B.ptr(table), B.ptr(offsets), B.ptr(pairs), st),
+                        "gs_isect_bin_scatter")
+        sc_ptr = ctypes.addressof(sc) if sc is not None else None
+        if uf:
+            # `counts` (the list lengths) becomes sorted_counts: the front kernel overwrites the long tiles' entries
+            with B.device_guard(dev), B.timed("gs_isect_tile_sort", dev):
+                B.check(lib.gs_isect_tile_sort_front_ex(C, tile_width, tile_height, B.ptr(offsets), n_isects, B.ptr(order),
+                                                        B.ptr(n_long), FRONT_K_TARGET, B.ptr(pairs), B.ptr(isect_ids),
+                                                        B.ptr(flatten_ids), B.ptr(counts), sc_ptr, st),
+                        "gs_isect_tile_sort_front")
+            fs = FrontSort((C, tile_width, tile_height), offsets, order, n_long, pairs, isect_ids, flatten_ids, counts)
+            fs.size_classes_host = sc
+            return isect_ids, flatten_ids, offsets, order, fs
+        with B.device_guard(dev), B.timed("gs_isect_tile_sort", dev):
+            B.check(lib.gs_isect_tile_sort_ex(C, tile_width, tile_height, B.ptr(offsets), n_isects, B.ptr(order),
+                                              B.ptr(n_long), B.ptr(pairs), B.ptr(isect_ids), B.ptr(flatten_ids), sc_ptr, st),
+                    "gs_isect_tile_sort")
+        return isect_ids, flatten_ids, offsets, order, None
+
     if fused:
         # one FFI call: count + offsets + tile order + the host read of n_isects (include/gsplat_mi355x.h, "composite
         # launches")
@@ -591,31 +704,48 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
                 if while_counting is not None:
                     while_counting()
                     while_counting = None
-                if POSTED_RESULTS:
-                    # the kernels post n_isects / the size classes themselves: no copy kernels, no stream
-                    # synchronisation, and the launches queued behind the producers (tile order) still run while the
-                    # host goes on
-                    B.check(lib.gs_host_post_wait(slot_addr, slot_addr + 8 if want_order else None, 10_000, st),
-                            "gs_host_post_wait")
-                    n_isects = int(slot_n[0])
-                    classes = list(slot_sc) if want_order else None
-                else:
-                    B.check(lib.gs_stream_synchronize(st), "gs_stream_synchronize")
-                    n_isects = int(host_n[0])
-                    classes = host_n.view(torch.int32)[2:5].tolist() if want_order else None
             except BaseException:
                 # kernels that post into this thread's slot may still be in flight: let them finish, or their values
                 # would land in the slot after the NEXT call has armed it and be taken for that call's results
                 lib.gs_stream_synchronize(st)
                 raise
-        if want_order:
-            # host copy of the tile order's size classes: launches for classes that hold no tile are skipped, and
-            # without a tile above 2048 entries there is no front to sort first
-            sc_host = (ctypes.c_int32 * 3)(*classes)
-            if sc_host[FRONT_FROM_CLASS] == 0:
-                use_front = False
-        if use_front:  # (cleared here, once it is known that a front will be sorted, not by the prepare call)
-            redo_flags = torch.zeros(C * T + 1, device=dev, dtype=torch.int32)
+
+        def wait_posted():
+            with B.device_guard(dev):
+                try:
+                    if POSTED_RESULTS:
+                        # the kernels post n_isects / the size classes themselves: no copy kernels, no stream
+                        # synchronisation, and the launches queued behind the producers (tile order) still run while
+                        # the host goes on
+                        B.check(lib.gs_host_post_wait(slot_addr, slot_addr + 8 if want_order else None, 10_000, st),
+                                "gs_host_post_wait")
+                        return int(slot_n[0]), (list(slot_sc) if want_order else None)
+                    B.check(lib.gs_stream_synchronize(st), "gs_stream_synchronize")
+                    return int(host_n[0]), (host_n.view(torch.int32)[2:5].tolist() if want_order else None)
+                except BaseException:
+                    lib.gs_stream_synchronize(st)  # (as above)
+                    raise
+
+        prev = _spec_table().get(spec_key) if (spec_key is not None and SPECULATE_SIZES and POSTED_RESULTS
+                                               and want_order) else None
+        if prev is not None and prev[0] > 0 and prev[1][0] == 0 and prev[1][FRONT_FROM_CLASS] == 0:
+            capacity = int(prev[0] * SPEC_MARGIN) + 1024
+            s_ids = torch.empty(capacity, device=dev, dtype=torch.int64) if want_ids else None
+            s_fids = torch.empty(capacity, device=dev, dtype=torch.int32)
+            s_pairs = torch.empty(capacity, device=dev, dtype=torch.int64)
+            with B.device_guard(dev):
+                B.check(lib.gs_isect_bin_build_dev(C, N, tile_width, tile_height, n_slices, group, regions,
+                                                   B.ptr(vis_list), B.ptr(vis_cnt), B.ptr(vis_masks), B.ptr(table),
+                                                   B.ptr(offsets), capacity, B.ptr(total), B.ptr(order), B.ptr(n_long),
+                                                   B.ptr(s_pairs), B.ptr(s_ids), B.ptr(s_fids),
+                                                   B.ptr(counts) if STAGED_SCATTER else None, st),
+                        "gs_isect_bin_build_dev")
+
+            return SpecLists(capacity, total, s_ids, s_fids, offsets, order, wait_posted, _build_lists, spec_key)
+        n_isects, classes = wait_posted()
+        if spec_key is not None and classes is not None:
+            _spec_table()[spec_key] = (n_isects, tuple(classes))
+        return _build_lists(n_isects, classes)
     else:
         with B.device_guard(dev), B.timed("gs_isect_bin_count", dev):
             B.check(lib.gs_isect_bin_count(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
@@ -631,59 +761,7 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
         if while_counting is not None:
             while_counting()
         n_isects = int(total.item())  # the one host sync of the pipeline (gsplat has the same one)
-        if want_order:  # (as the fused path: no front to sort first without a tile above 1024 entries)
-            sc_host = (ctypes.c_int32 * 3)(*n_long.tolist())
-            if sc_host[FRONT_FROM_CLASS] == 0:
-                use_front = False
-    need_ids = want_ids or use_front or sc_host is None or sc_host[0] > 0 or n_isects == 0
-    isect_ids = torch.empty(n_isects, device=dev, dtype=torch.int64) if need_ids else None
-    flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
-    if n_isects == 0:
-        return isect_ids, flatten_ids, offsets, None, None
-    pairs = torch.empty(n_isects, device=dev, dtype=torch.int64)
-    if fused:
-        with B.device_guard(dev):
-            B.check(lib.gs_isect_bin_build(C, N, tile_width, tile_height, n_slices, group, regions, B.ptr(vis_list),
-                                           B.ptr(vis_cnt), B.ptr(vis_masks), B.ptr(table), B.ptr(offsets), n_isects,
-                                           B.ptr(order), B.ptr(n_long), FRONT_K_TARGET if use_front else 0,
-                                           B.ptr(pairs), B.ptr(isect_ids), B.ptr(flatten_ids),
-                                           B.ptr(counts) if (STAGED_SCATTER or use_front) else None,
-                                           ctypes.addressof(sc_host) if sc_host is not None else None, st),
-                    "gs_isect_bin_build")
-        if use_front:
-            fs = FrontSort((C, tile_width, tile_height), offsets, order, n_long, pairs, isect_ids, flatten_ids, counts,
-                           redo_flags)
-            fs.size_classes_host = sc_host
-            return isect_ids, flatten_ids, offsets, order, fs
-        return isect_ids, flatten_ids, offsets, order, None
-    with B.device_guard(dev), B.timed("gs_isect_bin_scatter", dev):
-        if vis_list is not None:
-            B.check(lib.gs_isect_bin_scatter_regions(C, N, tile_width, tile_height, n_slices, group, regions,
-                                                     B.ptr(vis_list), B.ptr(vis_cnt), B.ptr(vis_masks), B.ptr(table),
-                                                     B.ptr(offsets), B.ptr(counts) if STAGED_SCATTER else None,
-                                                     B.ptr(pairs), st), "gs_isect_bin_scatter_regions")
-        else:
-            B.check(lib.gs_isect_bin_scatter(C, N, tile_width, tile_height, B.ptr(splats), B.ptr(tiles_per_gauss),
-                                             n_slices, B.ptr(table), B.ptr(offsets), B.ptr(pairs), st),
-                    "gs_isect_bin_scatter")
-    sc_ptr = ctypes.addressof(sc_host) if sc_host is not None else None
-    if use_front:
-        # `counts` (the list lengths) becomes sorted_counts: the front kernel overwrites the long tiles' entries
-        with B.device_guard(dev), B.timed("gs_isect_tile_sort", dev):
-            B.check(lib.gs_isect_tile_sort_front_ex(C, tile_width, tile_height, B.ptr(offsets), n_isects, B.ptr(order),
-                                                    B.ptr(n_long), FRONT_K_TARGET, B.ptr(pairs), B.ptr(isect_ids),
-                                                    B.ptr(flatten_ids), B.ptr(counts), sc_ptr, st),
-                    "gs_isect_tile_sort_front")
-        fs = FrontSort((C, tile_width, tile_height), offsets, order, n_long, pairs, isect_ids, flatten_ids, counts)
-        fs.size_classes_host = sc_host
-        return isect_ids, flatten_ids, offsets, order, fs
-    with B.device_guard(dev), B.timed("gs_isect_tile_sort", dev):
-        B.check(lib.gs_isect_tile_sort_ex(C, tile_width, tile_height, B.ptr(offsets), n_isects, B.ptr(order),
-                                          B.ptr(n_long), B.ptr(pairs), B.ptr(isect_ids), B.ptr(flatten_ids), sc_ptr, st),
-                "gs_isect_tile_sort")
-    return isect_ids, flatten_ids, offsets, order, None
-
-
+        return _build_lists(n_isects, n_long.tolist() if want_order else None)
 def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
     dev = B.require_gpu(isect_ids)
     offsets = torch.empty(n_cameras, tile_height, tile_width, device=dev, dtype=torch.int32)
@@ -791,11 +869,21 @@ class _RasterizeSplats(torch.autograd.Function):
                     with B.device_guard(dev):
                         B.check(B.lib().gs_fill_zero(B.ptr(v), v.numel() * 4, B.stream_handle(dev)), "gs_fill_zero")
 
+        spec = None
         if TW * TH <= bin_max_tiles():
-            isect_ids, flatten_ids, offsets, order, fs = isect_tiles_binned(
-                splats, tiles_per_gauss, TW, TH, front=FRONT_SORT,
-                cull_tile_size=tile_size if (cull and REGION_SCATTER) else 0, while_counting=prepare_outputs,
-                want_ids=not (cull and REGION_SCATTER))  # (culled lists are internal: meta builds gsplat's own on demand)
+            culled = bool(cull and REGION_SCATTER)
+            lists = isect_tiles_binned(
+                splats, tiles_per_gauss, TW, TH, front=FRONT_SORT, cull_tile_size=tile_size if culled else 0,
+                while_counting=prepare_outputs,
+                want_ids=not culled,  # (culled lists are internal: meta builds gsplat's own on demand)
+                spec_key=(dev.index, C, N, width, height, channels, culled))
+            if isinstance(lists, SpecLists):
+                # speculatively sized lists: the forward rasterizer is queued on them before the host has looked at
+                # this call's intersection count (include/gsplat_mi355x.h, "device-side n_isects")
+                spec = lists
+                isect_ids, flatten_ids, offsets, order = spec.isect_ids, spec.flatten_ids, spec.offsets, spec.order
+            else:
+                isect_ids, flatten_ids, offsets, order, fs = lists
         else:
             order = None
             isect_ids, flatten_ids = isect_tiles_from_splats(splats, tiles_per_gauss, TW, TH)
@@ -803,7 +891,7 @@ class _RasterizeSplats(torch.autograd.Function):
             prepare_outputs()
         bg = B.f32c(backgrounds) if backgrounds is not None else None
         rc, ra, last_ids, final_T = out["rc"], out["ra"], out["last_ids"], out["final_T"]
-        n_isects = flatten_ids.numel()
+        n_isects = flatten_ids.numel()  # (speculative lists: their capacity, > 0, until `spec.resolve()` below)
         ctx.v_splats, ctx.v_ready = out["v_splats"], None
         if ctx.v_splats is not None and ctx.v_splats.numel() * 4 > SIDE_STREAM_MIN_BYTES:
             # large record: zero it on a side stream, where the HBM-bound fill hides behind the issue-bound forward
@@ -830,8 +918,38 @@ class _RasterizeSplats(torch.autograd.Function):
             with B.device_guard(dev), B.timed("gs_raster_tile_order", dev):
                 B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, None, B.ptr(order), None,
                                                      B.stream_handle(dev)), "gs_raster_tile_order")
-        launch_raster_fwd(splats, offsets, flatten_ids, order, fs, bg, (C, N, width, height, tile_size, channels, ed),
-                          rc, ra, last_ids, work, None, final_T)
+        geom = (C, N, width, height, tile_size, channels, ed)
+        if spec is not None:
+            with B.device_guard(dev):
+                status = B.lib().gs_rasterize_fwd_dev(C, width, height, tile_size, channels, B.ptr(splats),
+                                                      B.ptr(offsets), B.ptr(flatten_ids), spec.capacity,
+                                                      B.ptr(spec.total), B.ptr(bg), int(ed), B.ptr(rc), B.ptr(ra),
+                                                      B.ptr(last_ids), B.ptr(order), B.ptr(work), None, N,
+                                                      B.ptr(final_T), B.stream_handle(dev))
+            # GS_ERR_CONTRACT here: a speculative sort launch has already met a list beyond its buffer (a tile list
+            # above 6144 entries without the key array as scratch) -- a failed speculation, which resolve() reports too
+            # (size class 0 is not empty), not an error of this call
+            if status != B.GS_ERR_CONTRACT:
+                B.check(status, "gs_rasterize_fwd_dev")
+            if spec.resolve() and status == 0:
+                isect_ids, flatten_ids = spec.isect_ids, spec.flatten_ids
+            else:
+                # the count did not fit the capacity (or a list was too long for the speculative sort): nothing was
+                # written; the same launches again on lists of the exact size
+                isect_ids, flatten_ids, offsets, order, fs = spec.redo()
+                if flatten_ids.numel() == 0:
+                    order = work = None
+                elif order is None and n_tiles <= 131072:
+                    order = torch.empty(n_tiles, device=dev, dtype=torch.int32)
+                    with B.device_guard(dev):
+                        B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), flatten_ids.numel(), None,
+                                                             B.ptr(order), None, B.stream_handle(dev)),
+                                "gs_raster_tile_order")
+                launch_raster_fwd(splats, offsets, flatten_ids, order, fs, bg, geom, rc, ra, last_ids, work, None,
+                                  final_T)
+            n_isects = flatten_ids.numel()
+        else:
+            launch_raster_fwd(splats, offsets, flatten_ids, order, fs, bg, geom, rc, ra, last_ids, work, None, final_T)
         _tls.front_sort = fs
         _tls.last_tile_work = work  # (diagnostics: bench.py sums it into the list entries the backward walks)
         _tls.raster_state = (splats, offsets, isect_ids, flatten_ids, order, fs)  # handed to rasterization() for the lazy completion of meta["isect_ids"/"flatten_ids"]

@@ -449,6 +449,34 @@ int gs_rasterize_fwd_front(int32_t C, int32_t width, int32_t height, int32_t til
                            int32_t* sorted_counts, int32_t* redo_flags, const float* opacity_override,
                            int32_t n_per_camera, float* final_T, const int32_t* size_classes, uint64_t* pairs,
                            int64_t* isect_ids, const int32_t* size_classes_host /* or NULL */, void* stream);
+/* ---- device-side n_isects (no reference counterpart: gsplat reads the count on the host, as the entry points above do)
+ * The count of intersections sizes the pair / id arrays, so the host of the entry points above waits for it in the middle
+ * of the forward -- on launch-bound shapes (the reference's own step: one camera, base.py:393-411) the GPU then idles
+ * until the host has issued the rest.  These two variants take the count from DEVICE memory (`n_isects_dev` = the
+ * `total` output of gs_isect_bin_prepare) and a host-chosen `capacity` (>= 1) that the arrays were allocated with --
+ * normally a little above the last step's count:
+ *   gs_isect_bin_build_dev  = gs_isect_bin_scatter_regions + gs_isect_tile_sort (every list whole, all four size
+ *                             classes launched; isect_ids may be NULL, and then a list above 6144 entries raises the
+ *                             contract flag: gs_contract_status) with pairs / flatten_ids (/ isect_ids) of `capacity`
+ *   gs_rasterize_fwd_dev    = gs_rasterize_fwd (no front-sorted lists) on such arrays
+ * If *n_isects_dev > capacity the kernels write NOTHING (no list, no pixel): the caller reads the posted count once
+ * the launches are issued (gs_host_post_wait: no stall, the producer finished long before) and, on overflow, repeats
+ * the two calls with arrays of the right size.  With *n_isects_dev <= capacity the results are bit-identical to the
+ * exact-size entry points; the elements of the arrays beyond the count are not written. */
+int gs_isect_bin_build_dev(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, int32_t n_slices,
+                           int32_t slices_per_group, int32_t n_regions, const uint64_t* vis_list,
+                           const int32_t* vis_counts, const uint64_t* vis_masks, const uint32_t* table,
+                           const int32_t* isect_offsets, int64_t capacity, const int64_t* n_isects_dev,
+                           const int32_t* tile_order, const int32_t* size_classes, uint64_t* pairs,
+                           int64_t* isect_ids /* [capacity] or NULL */, int32_t* flatten_ids /* [capacity] */,
+                           const int32_t* tile_counts /* or NULL: direct 8-B stores */, void* stream);
+int gs_rasterize_fwd_dev(int32_t C, int32_t width, int32_t height, int32_t tile_size, int32_t channels,
+                         const float* splats, const int32_t* isect_offsets, const int32_t* flatten_ids,
+                         int64_t capacity, const int64_t* n_isects_dev, const float* backgrounds,
+                         int32_t ed_last_channel, float* render_colors, float* render_alphas, int32_t* last_ids,
+                         const int32_t* tile_order, int32_t* tile_work, const float* opacity_override,
+                         int32_t n_per_camera, float* final_T, void* stream);
+
 /* The three sort entry points with a HOST copy of size_classes (from gs_isect_bin_prepare; NULL = as the plain entry
  * points): launches for size classes that hold no tile are skipped -- on launch-bound shapes only the shortest class
  * exists, and a launch that finds nothing to do still costs microseconds.  gs_isect_tile_sort_front_ex with no tile
