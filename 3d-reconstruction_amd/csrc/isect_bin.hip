@@ -1396,24 +1396,22 @@ extern "C" int gs_isect_tile_sort(int32_t C, int32_t tile_w, int32_t tile_h, con
 
 // gs_isect_bin_scatter_regions + gs_isect_tile_sort for a host that has NOT read n_isects yet (include/gsplat_mi355x.h,
 // "device-side n_isects"): `capacity` sizes pairs / flatten_ids (/ isect_ids), the count is read from *n_isects_dev by
-// the kernels; every list is sorted whole, by the launches of all four size classes or of those the host's hint expects
-// to hold tiles.  A count beyond the capacity leaves the arrays untouched.
+// the kernels; all four size classes are launched (the host does not know which ones hold tiles) and every list is sorted
+// whole.  A count beyond the capacity leaves the arrays untouched.
 extern "C" int gs_isect_bin_build_dev(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, int32_t n_slices,
                                       int32_t slices_per_group, int32_t n_regions, const uint64_t* vis_list,
                                       const int32_t* vis_counts, const uint64_t* vis_masks, const uint32_t* table,
                                       const int32_t* isect_offsets, int64_t capacity, const int64_t* n_isects_dev,
                                       const int32_t* tile_order, const int32_t* size_classes, uint64_t* pairs,
                                       int64_t* isect_ids, int32_t* flatten_ids, const int32_t* tile_counts,
-                                      const int32_t* size_classes_hint_host, void* stream) {
+                                      void* stream) {
   if (!n_isects_dev || capacity < 1 || !tile_order || !size_classes) return GS_ERR_INVALID_ARG;
   int st = scatter_regions_impl(C, N, tile_w, tile_h, n_slices, slices_per_group, n_regions, vis_list, vis_counts,
                                 vis_masks, table, isect_offsets, tile_counts, pairs, n_isects_dev, capacity, stream);
   if (st != GS_OK) return st;
   if (N == 0) return GS_OK;
-  // (the hint: size classes the caller EXPECTS -- launches of classes it calls empty are skipped, and the caller must
-  // compare the posted classes with it afterwards: a class that holds tiles but was not launched is not sorted)
   return tile_sort_impl(C, tile_w, tile_h, isect_offsets, capacity, tile_order, size_classes, pairs, isect_ids,
-                        flatten_ids, size_classes_hint_host, stream, n_isects_dev);
+                        flatten_ids, nullptr, stream, n_isects_dev);
 }
 
 extern "C" int gs_isect_tile_sort_ex(int32_t C, int32_t tile_w, int32_t tile_h, const int32_t* isect_offsets,

@@ -73,7 +73,7 @@ _SIGNATURES = {
     "gs_host_post_alloc": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), c_int64]),
     "gs_host_post_free": (ctypes.c_int, [_P]),
     "gs_contract_status": (ctypes.c_int, [c_int32]),
-    "gs_isect_bin_build_dev": (ctypes.c_int, [c_int32] * 7 + [_P] * 5 + [c_int64] + [_P] * 9),
+    "gs_isect_bin_build_dev": (ctypes.c_int, [c_int32] * 7 + [_P] * 5 + [c_int64] + [_P] * 8),
     "gs_rasterize_fwd_dev": (ctypes.c_int, [c_int32] * 5 + [_P, _P, _P, c_int64, _P, _P, c_int32] + [_P] * 6 +
                              [c_int32, _P, _P]),
     "gs_host_post_wait": (ctypes.c_int, [_P, _P, c_int32, _P]),

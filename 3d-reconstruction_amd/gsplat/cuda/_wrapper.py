@@ -545,9 +545,8 @@ class SpecLists:
     that read the lists have been queued -- waits for the posted count (already there) and says whether the speculation
     held; if not, `redo()` builds the lists again through the exact-size path."""
 
-    def __init__(self, capacity, total, isect_ids, flatten_ids, offsets, order, wait_posted, build_exact, key, hint,
-                 n_tiles):
-        self.capacity, self.total, self.hint, self.n_tiles = capacity, total, hint, n_tiles
+    def __init__(self, capacity, total, isect_ids, flatten_ids, offsets, order, wait_posted, build_exact, key):
+        self.capacity, self.total = capacity, total
         self.isect_ids, self.flatten_ids, self.offsets, self.order = isect_ids, flatten_ids, offsets, order
         self._wait, self._build, self._key = wait_posted, build_exact, key
         self.n_isects = self.classes = None
@@ -556,14 +555,6 @@ class SpecLists:
         self.n_isects, self.classes = self._wait()
         _spec_table()[self._key] = (self.n_isects, tuple(self.classes))
         ok = 0 < self.n_isects <= self.capacity and (self.classes[0] == 0 or self.isect_ids is not None)
-        # every size class that holds tiles must have been launched (class c = [sc[c-1], sc[c]) of the longest-first order)
-        lo_a = lo_h = 0
-        for c in range(4):
-            hi_a = self.classes[c] if c < 3 else self.n_tiles
-            hi_h = self.hint[c] if c < 3 else self.n_tiles
-            if hi_a > lo_a and not hi_h > lo_h:
-                ok = False
-            lo_a, lo_h = hi_a, hi_h
         if ok:
             n = self.n_isects
             self.flatten_ids = self.flatten_ids[:n]
@@ -742,18 +733,15 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
             s_ids = torch.empty(capacity, device=dev, dtype=torch.int64) if want_ids else None
             s_fids = torch.empty(capacity, device=dev, dtype=torch.int32)
             s_pairs = torch.empty(capacity, device=dev, dtype=torch.int64)
-            hint = (ctypes.c_int32 * 3)(*prev[1])  # the last call's size classes: launch the classes it had
             with B.device_guard(dev):
                 B.check(lib.gs_isect_bin_build_dev(C, N, tile_width, tile_height, n_slices, group, regions,
                                                    B.ptr(vis_list), B.ptr(vis_cnt), B.ptr(vis_masks), B.ptr(table),
                                                    B.ptr(offsets), capacity, B.ptr(total), B.ptr(order), B.ptr(n_long),
                                                    B.ptr(s_pairs), B.ptr(s_ids), B.ptr(s_fids),
-                                                   B.ptr(counts) if STAGED_SCATTER else None,
-                                                   ctypes.addressof(hint), st),
+                                                   B.ptr(counts) if STAGED_SCATTER else None, st),
                         "gs_isect_bin_build_dev")
 
-            return SpecLists(capacity, total, s_ids, s_fids, offsets, order, wait_posted, _build_lists, spec_key,
-                             tuple(prev[1]), C * T)
+            return SpecLists(capacity, total, s_ids, s_fids, offsets, order, wait_posted, _build_lists, spec_key)
         n_isects, classes = wait_posted()
         if spec_key is not None and classes is not None:
             _spec_table()[spec_key] = (n_isects, tuple(classes))

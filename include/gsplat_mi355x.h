@@ -455,13 +455,9 @@ int gs_rasterize_fwd_front(int32_t C, int32_t width, int32_t height, int32_t til
  * until the host has issued the rest.  These two variants take the count from DEVICE memory (`n_isects_dev` = the
  * `total` output of gs_isect_bin_prepare) and a host-chosen `capacity` (>= 1) that the arrays were allocated with --
  * normally a little above the last step's count:
- *   gs_isect_bin_build_dev  = gs_isect_bin_scatter_regions + gs_isect_tile_sort (every list whole; isect_ids may be
- *                             NULL, and then a list above 6144 entries raises the contract flag: gs_contract_status)
- *                             with pairs / flatten_ids (/ isect_ids) of `capacity`.  size_classes_hint_host (int32[3]
- *                             as gs_isect_bin_prepare's size_classes_host, or NULL = launch all four classes): the
- *                             classes the caller EXPECTS; a class the hint calls empty is not launched, so the caller
- *                             must compare the posted classes with its hint and repeat the call if a class it did
- *                             not expect holds tiles
+ *   gs_isect_bin_build_dev  = gs_isect_bin_scatter_regions + gs_isect_tile_sort (every list whole, all four size
+ *                             classes launched; isect_ids may be NULL, and then a list above 6144 entries raises the
+ *                             contract flag: gs_contract_status) with pairs / flatten_ids (/ isect_ids) of `capacity`
  *   gs_rasterize_fwd_dev    = gs_rasterize_fwd (no front-sorted lists) on such arrays
  * If *n_isects_dev > capacity the kernels write NOTHING (no list, no pixel): the caller reads the posted count once
  * the launches are issued (gs_host_post_wait: no stall, the producer finished long before) and, on overflow, repeats
@@ -473,8 +469,7 @@ int gs_isect_bin_build_dev(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h,
                            const int32_t* isect_offsets, int64_t capacity, const int64_t* n_isects_dev,
                            const int32_t* tile_order, const int32_t* size_classes, uint64_t* pairs,
                            int64_t* isect_ids /* [capacity] or NULL */, int32_t* flatten_ids /* [capacity] */,
-                           const int32_t* tile_counts /* or NULL: direct 8-B stores */,
-                           const int32_t* size_classes_hint_host /* or NULL */, void* stream);
+                           const int32_t* tile_counts /* or NULL: direct 8-B stores */, void* stream);
 int gs_rasterize_fwd_dev(int32_t C, int32_t width, int32_t height, int32_t tile_size, int32_t channels,
                          const float* splats, const int32_t* isect_offsets, const int32_t* flatten_ids,
                          int64_t capacity, const int64_t* n_isects_dev, const float* backgrounds,

@@ -169,35 +169,3 @@ def test_a_list_too_long_for_the_speculative_sort_is_redone(gpu_device):
         assert B.lib().gs_contract_status(0) == 0
     finally:
         W.SPECULATE_SIZES = saved
-
-
-def test_a_size_class_the_hint_did_not_expect_is_redone(gpu_device):
-    """The speculative sort launches only the size classes the last call had.  History says "every list has at most 512
-    entries"; the scene has lists between 513 and 2048: those classes were not launched, the call is redone."""
-    import gsplat.cuda._wrapper as W
-
-    dev = gpu_device
-    N, Wd, Hd = 60_000, 96, 64
-    g = _dense_scene(N, 0.3, 0.95, seed=9)
-    vm, Ks = synth_scene.make_cameras(1, Wd, Hd)
-    wts = _weights(dev, 1, Hd, Wd, 6)
-    saved = W.SPECULATE_SIZES
-    try:
-        W.SPECULATE_SIZES = False
-        ref = _step(dev, g, vm, Ks, Wd, Hd, wts)
-        W.SPECULATE_SIZES = True
-        W._spec_table().clear()
-        _step(dev, g, vm, Ks, Wd, Hd, wts)
-        table = W._spec_table()
-        (key, (n, classes)), = table.items()
-        assert classes[0] == 0 and classes[2] > 0, f"scene must have lists in 513..2048 and none above: {classes}"
-        table[key] = (n, (0, 0, 0))
-        with _Spy(W) as spy:
-            out = _step(dev, g, vm, Ks, Wd, Hd, wts)
-            assert len(spy.results) == 1 and spy.results[0][0] is False and spy.results[0][1] <= spy.results[0][2]
-            nxt = _step(dev, g, vm, Ks, Wd, Hd, wts)   # history is right again: speculation holds
-            assert spy.results[1][0] is True
-        _same(out, ref)
-        _same(nxt, ref)
-    finally:
-        W.SPECULATE_SIZES = saved
