@@ -528,8 +528,13 @@ SIDE_STREAM_MIN_BYTES = 32 << 20
 # that has a tile list the speculative launches could not sort -- is redone through the exact-size path.  Same bits
 # either way.  Only taken when the previous call of the shape had no tile list above 2048 entries (those shapes are
 # GPU-bound and want the front-first sort, whose launches depend on the host knowing the size classes).
+# Every size class of the sort is launched on speculative lists -- a class that was not launched would leave its lists'
+# ids unwritten and the rasterizer would gather through them (tried with a host hint of the expected classes: a GPU
+# fault, profiles/r03_ab_runs.txt item 2) -- which costs two launches that find nothing to do; on GPU-bound shapes
+# that is all speculation changes (configs[1]: +0.004 ms), so it is used up to SPEC_MAX_ROWS (camera, Gaussian) rows.
 SPECULATE_SIZES = True
 SPEC_MARGIN = 1.25
+SPEC_MAX_ROWS = 3_500_000
 _spec_tls = threading.local()
 
 
@@ -727,7 +732,7 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
                     raise
 
         prev = _spec_table().get(spec_key) if (spec_key is not None and SPECULATE_SIZES and POSTED_RESULTS
-                                               and want_order) else None
+                                               and want_order and C * N <= SPEC_MAX_ROWS) else None
         if prev is not None and prev[0] > 0 and prev[1][0] == 0 and prev[1][FRONT_FROM_CLASS] == 0:
             capacity = int(prev[0] * SPEC_MARGIN) + 1024
             s_ids = torch.empty(capacity, device=dev, dtype=torch.int64) if want_ids else None

@@ -358,7 +358,7 @@ def main():
 
     if args.no_cull:
         Wm.CULL_LISTS = False
-    for name in ("SLICES_TOTAL", "SCATTER_REGIONS", "SCATTER_WORKGROUPS", "STAGED_SCATTER", "FRONT_FROM_CLASS", "POSTED_RESULTS", "FRONT_SORT"):  # launch-shape sweeps (scratch/)
+    for name in ("SLICES_TOTAL", "SCATTER_REGIONS", "SCATTER_WORKGROUPS", "STAGED_SCATTER", "FRONT_FROM_CLASS", "POSTED_RESULTS", "FRONT_SORT", "SPECULATE_SIZES"):  # launch-shape sweeps (scratch/)
         if os.environ.get("GS_" + name):
             setattr(Wm, name, int(os.environ["GS_" + name]))
     if render:
