@@ -5,7 +5,7 @@ import torch
 import synth_scene
 from gsplat.rendering import rasterization
 dev = torch.device("cuda:0")
-N, W, H = 2000, 160, 96
+N, W, H = (int(os.environ.get("PH_N", 2000)), int(os.environ.get("PH_W", 160)), int(os.environ.get("PH_H", 96)))
 g = {k: v.to(dev).requires_grad_(True) for k, v in synth_scene.make_gaussians(N, sh_degree=None, extent=10.0).items()}
 vm, Ks = (t.to(dev) for t in synth_scene.make_cameras(1, W, H))
 def fwd():
