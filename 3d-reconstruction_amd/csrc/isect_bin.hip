@@ -1157,24 +1157,14 @@ static inline int bin_ilog2_floor(int64_t v) {
 
 }  // namespace gs
 
-#ifndef GS_TS_W2
-#define GS_TS_W2 4
-#endif
-#ifndef GS_TS_W3
-#define GS_TS_W3 2
-#endif
-#ifndef GS_TS_G2
+// launch shapes of the per-tile sort's size classes (waves per list, grid multiples of 256) and the LDS budget of the
+// staged region scatter; each value is the best of a sweep on the box (profiles/r02_ab_runs.txt)
+#define GS_TS_W1 8   // 1025..2048 entries: few lists, each a latency chain
+#define GS_TS_W2 4   // 513..1024
+#define GS_TS_W3 2   // <= 512
 #define GS_TS_G2 16
-#endif
-#ifndef GS_TS_G3
 #define GS_TS_G3 14
-#endif
-#ifndef GS_TS_W1  // waves per list of the 1025..2048 class (few lists, each a latency chain: see DESIGN.md section 6)
-#define GS_TS_W1 8
-#endif
-#ifndef GS_SCATTER_LDS  // LDS bytes of the staged region scatter (cursors + staging area), one workgroup per CU
-#define GS_SCATTER_LDS (163840 - 256)
-#endif
+#define GS_SCATTER_LDS (163840 - 256)  // cursors + staging area, one workgroup per CU
 static int bin_check(int32_t C, int32_t N, int32_t tile_w, int32_t tile_h, int32_t n_slices) {
   if (C < 1 || N < 0 || tile_w < 1 || tile_h < 1 || n_slices < 1) return GS_ERR_INVALID_ARG;
   if ((int64_t)tile_w * tile_h > gs::BIN_MAX_TILES) return GS_ERR_UNSUPPORTED;

@@ -191,11 +191,7 @@ __global__ __launch_bounds__(256, (CMODE == GS_COLOR_SH && DEG == 4) ? 1 : 4) vo
   const int n_words = (p.N + 63) >> 6;
   float* tile = s_tile[threadIdx.x >> 6];
   float mu[3];
-#ifdef GS_EXP_NOCOOP_FWD
-  const bool coop_ok = false;
-#else
   const bool coop_ok = true;
-#endif
   load3(means, coop_ok && aligned16(means), n, row0, rows, lane, tile, mu);
   // SH coefficients: the whole row up front (aligned float4 loads in flight behind the geometry), not inside the
   // per-camera branch where every visible camera would wait for them again
@@ -369,11 +365,7 @@ __global__ __launch_bounds__(256, SHSPLIT ? 4 : 2) void projection_bwd_kernel(
   const int64_t row0_3 = n_raw - lane3;
   const int rows3 = (int)max((int64_t)0, min((int64_t)64, (int64_t)p.N - row0_3));  // wave-uniform
   // (measured: the cooperative [N,3] transfers that help the forward cost this kernel 0.004-0.006 ms)
-#ifdef GS_EXP_COOP_BWD
-  const bool coop3 = rows3 > 0;
-#else
   const bool coop3 = false;
-#endif
   float mu[3];
   load3(means, aligned16(means) && coop3, n, row0_3, rows3, lane3, tile3, mu);
   const float opac = opacities[n];
@@ -412,13 +404,10 @@ __global__ __launch_bounds__(256, SHSPLIT ? 4 : 2) void projection_bwd_kernel(
 
   // the radii of up to RCH cameras are fetched together, ahead of the camera loop: one dependent round trip
   // (radius -> branch -> record loads) fewer per camera
-#ifndef GS_EXP_NO_RADII_PREFETCH
   constexpr int RCH = 8;
   int rad[RCH];
-#endif
   for (int c = 0; c < p.C; ++c) {
     const int64_t idx = (int64_t)c * p.N + n;
-#ifndef GS_EXP_NO_RADII_PREFETCH
     if ((c % RCH) == 0) {
 #pragma unroll
       for (int k = 0; k < RCH; ++k) rad[k] = (c + k < p.C) ? radii[(int64_t)(c + k) * p.N + n] : 0;
@@ -427,9 +416,6 @@ __global__ __launch_bounds__(256, SHSPLIT ? 4 : 2) void projection_bwd_kernel(
 #pragma unroll
     for (int k = 1; k < RCH; ++k) rc = ((c % RCH) == k) ? rad[k] : rc;
     const bool vis = live && (rc > 0);
-#else
-    const bool vis = live && (radii[idx] > 0);
-#endif
     int64_t pack_row = 0;  // SHSPLIT: this pair's row of the packed values
     if constexpr (SHSPLIT) {
       const unsigned long long vb = __ballot(vis);

@@ -108,16 +108,11 @@ struct MsgLayoutSh {
   int64_t campos, words, prefix, vals;
 };
 
-#ifndef GS_EXP_SHP_WAVES
-#define GS_EXP_SHP_WAVES 1
-#endif
-#ifndef GS_EXP_SHP_MODE
-// 0: coefficient pointer inside the visible branch, 1: aligned row load inside the branch, 2: row prefetched up front.
-// Measured at configs[1] (scratch/run_exp2.sh): 0.096 / 0.097 / 0.113-0.115 ms -- the prefetch costs a wave per SIMD.
-#define GS_EXP_SHP_MODE 1
-#endif
+// The Gaussian's coefficient row (needed for the view-direction gradient) is loaded as aligned float4s inside the
+// visible branch.  Measured at configs[1] (scratch/run_exp2.sh): 0.097 ms; through the plain pointer 0.096; prefetched
+// up front for every Gaussian some camera sees 0.113-0.115 ms -- the prefetch costs a wave per SIMD.
 template <int DEG, bool VIEWGRAD>
-__global__ __launch_bounds__(256, DEG == 3 ? GS_EXP_SHP_WAVES : 1) void sh_bwd_packed_kernel(
+__global__ __launch_bounds__(256, 1) void sh_bwd_packed_kernel(
     int N, int K, int C, int n_msgs, int64_t msg_stride, int64_t cap, MsgLayoutSh L, const float* __restrict__ means,
     const float* __restrict__ coeffs, const unsigned char* __restrict__ msgs, float* __restrict__ v_coeffs,
     float* __restrict__ v_means, int accumulate_means, int local_msg, float* __restrict__ v_campos) {
@@ -137,21 +132,6 @@ __global__ __launch_bounds__(256, DEG == 3 ? GS_EXP_SHP_WAVES : 1) void sh_bwd_p
 #pragma unroll
   for (int k = 0; k < NB * 3; ++k) acc[k] = 0.f;
   float vmx = 0.f, vmy = 0.f, vmz = 0.f;
-  // is this Gaussian visible to any camera of any message?  Then its coefficient row (needed for the view-direction
-  // gradient) is loaded ONCE, up front, as aligned float4s -- not again inside every visible camera's branch
-#if GS_EXP_SHP_MODE == 2
-  bool any_vis = false;
-  for (int m = 0; m < n_msgs && has_word; ++m) {
-    const unsigned char* msg = msgs + (int64_t)m * msg_stride;
-    const uint64_t* words = reinterpret_cast<const uint64_t*>(msg + L.words);
-    const int n_cams = min(max(__builtin_amdgcn_readfirstlane(*reinterpret_cast<const int32_t*>(msg)), 0), C);
-    for (int c = 0; c < n_cams; ++c) any_vis |= ((words[(int64_t)c * n_words + w] >> lane) & 1ull) != 0ull;
-  }
-  float creg[NB * 3];
-#pragma unroll
-  for (int k = 0; k < NB * 3; ++k) creg[k] = 0.f;
-  if (live && any_vis && DEG >= 1) sh_load_row<NB * 3>(coeffs + (int64_t)n * K * 3, (K % 4 == 0) && aligned16(coeffs), creg);
-#endif
   for (int m = 0; m < n_msgs && has_word; ++m) {
     const unsigned char* msg = msgs + (int64_t)m * msg_stride;
     const uint64_t* words = reinterpret_cast<const uint64_t*>(msg + L.words);
@@ -168,12 +148,8 @@ __global__ __launch_bounds__(256, DEG == 3 ? GS_EXP_SHP_WAVES : 1) void sh_bwd_p
           const int64_t row = (int64_t)prefix[(int64_t)c * n_words + w] + __popcll(word & lt_mask);
           if (row >= 0 && row < cap) {  // (always, for a well-formed message: cap >= its visible pairs)
             const float v[3] = {vals[3 * row], vals[3 * row + 1], vals[3 * row + 2]};
-#if GS_EXP_SHP_MODE == 0
-            const float* creg = coeffs + (int64_t)n * K * 3;
-#elif GS_EXP_SHP_MODE == 1
             float creg[NB * 3];
             sh_load_row<NB * 3>(coeffs + (int64_t)n * K * 3, (K % 4 == 0) && aligned16(coeffs), creg);
-#endif
             sh_eval_vjp<DEG, true>(creg, mu[0] - cps[3 * c], mu[1] - cps[3 * c + 1], mu[2] - cps[3 * c + 2], v, acc,
                                    gx, gy, gz);
             vmx += gx; vmy += gy; vmz += gz;
