@@ -18,6 +18,13 @@
                           Pins oracle/loss_ref.py (tests/test_oracle_cpu.py) and the HIP loss kernels
                           (tests/test_gpu_losses.py).
 
+  rigid_ref.npz           the rigid nodes' local -> world transform (models/nodes/rigid.py:426-470: R(quat_act(q_inst)) mean
+                          + t_inst, quat_act(q_inst) (x) quat_act(q)) evaluated with the REFERENCE's own helpers from
+                          utils/geometry.py: quat_to_rotmat (:116-152, the one rigid.py binds) and
+                          safe_quaternion_multiply (:170-216, the same Hamilton product as models/gaussians/basics.py:64-74
+                          `quat_mult`, whose module cannot be imported here), with gradients of a fixed linear loss.
+                          Pins gsplat.prepass.rigid_transform (tests/test_gpu_prepass.py).
+
     python tests/golden/make_golden.py
 """
 import importlib.util
@@ -107,6 +114,29 @@ def sh_golden():
     np.savez_compressed(os.path.join(HERE, "sh_fp64.npz"), **out)
 
 
+def rigid_golden():
+    spec = importlib.util.spec_from_file_location("ref_geometry", REF_GEOMETRY)
+    geo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(geo)
+    n, n_inst = 3001, 11
+    g = torch.Generator().manual_seed(31)
+    means, quats = torch.randn(n, 3, generator=g) * 2, torch.randn(n, 4, generator=g)
+    iq, it = torch.randn(n_inst, 4, generator=g) * 1.3, torch.randn(n_inst, 3, generator=g) * 10
+    pid = torch.randint(0, n_inst, (n, 1), generator=g).sort(dim=0).values
+    wm_w, wq_w = torch.randn(n, 3, generator=g), torch.randn(n, 4, generator=g)
+    ref = [t.double().requires_grad_(True) for t in (means, quats, iq, it)]
+    quat_act = lambda x: x / x.norm(dim=-1, keepdim=True)          # vanilla.py:136-137
+    rot_per_pts = geo.quat_to_rotmat(quat_act(ref[2]))[pid[..., 0]]  # rigid.py:426-429
+    wm = torch.bmm(rot_per_pts, ref[0].unsqueeze(-1)).squeeze(-1) + ref[3][pid[..., 0]]   # :447-453
+    wq = geo.safe_quaternion_multiply(quat_act(ref[2][pid[..., 0]]), quat_act(ref[1]))     # :464-470
+    ((wm * wm_w.double()).sum() + (wq * wq_w.double()).sum()).backward()
+    np.savez_compressed(os.path.join(HERE, "rigid_ref.npz"), means=means.numpy(), quats=quats.numpy(),
+                        inst_quats=iq.numpy(), inst_trans=it.numpy(), point_ids=pid.numpy(), wm_w=wm_w.numpy(),
+                        wq_w=wq_w.numpy(), world_means=wm.detach().numpy(), world_quats=wq.detach().numpy(),
+                        grad_means=ref[0].grad.numpy(), grad_quats=ref[1].grad.numpy(),
+                        grad_inst_quats=ref[2].grad.numpy(), grad_inst_trans=ref[3].grad.numpy())
+
+
 def losses_golden():
     spec = importlib.util.spec_from_file_location("ref_losses", REF_LOSSES)
     ref = importlib.util.module_from_spec(spec)
@@ -185,6 +215,7 @@ def losses_golden():
 
 if __name__ == "__main__":
     quat_golden()
+    rigid_golden()
     losses_golden()
     pipeline_golden()
     sh_golden()

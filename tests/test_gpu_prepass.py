@@ -271,3 +271,27 @@ def test_rigid_class_chains_into_collect_and_render(gpu_device):
     for name, t in (("inst_quats", inst_q), ("inst_trans", inst_t), ("means", raw["means"]), ("quats", raw["quats"]),
                     ("features_rest", raw["features_rest"])):
         assert t.grad is not None and torch.isfinite(t.grad).all() and float(t.grad.abs().sum()) > 0, name
+
+
+def test_rigid_transform_matches_reference_fixture(gpu_device):
+    """gsplat.prepass.rigid_transform against vectors made with the REFERENCE's own helpers (utils/geometry.py
+    quat_to_rotmat and safe_quaternion_multiply, tests/golden/make_golden.py::rigid_golden) on rigid.py:426-470's lines:
+    world means / quaternions and the gradients of all four inputs."""
+    import os
+
+    import numpy as np
+
+    from gsplat.prepass import rigid_transform
+
+    dev = gpu_device
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "rigid_ref.npz"))
+    f = lambda k: torch.from_numpy(z[k]).float().to(dev)
+    got = [f(k).requires_grad_(True) for k in ("means", "quats", "inst_quats", "inst_trans")]
+    gm, gq = rigid_transform(got[0], got[1], torch.from_numpy(z["point_ids"]).to(dev), got[2], got[3], validate=True)
+    assert torch.allclose(gm.detach().cpu().double(), torch.from_numpy(z["world_means"]), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(gq.detach().cpu().double(), torch.from_numpy(z["world_quats"]), rtol=1e-5, atol=1e-6)
+    ((gm * f("wm_w")).sum() + (gq * f("wq_w")).sum()).backward()
+    for name, a in zip(("means", "quats", "inst_quats", "inst_trans"), got):
+        ref = torch.from_numpy(z["grad_" + name])
+        rel = float((a.grad.cpu().double() - ref).norm() / ref.norm())
+        assert rel < 1e-5, (name, rel)
