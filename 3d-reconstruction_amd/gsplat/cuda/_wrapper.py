@@ -881,7 +881,8 @@ class _RasterizeSplats(torch.autograd.Function):
                 splats, tiles_per_gauss, TW, TH, front=FRONT_SORT, cull_tile_size=tile_size if culled else 0,
                 while_counting=prepare_outputs,
                 want_ids=not culled,  # (culled lists are internal: meta builds gsplat's own on demand)
-                spec_key=(dev.index, C, N, width, height, channels, culled))
+                # (N is not part of the key: densification changes it every refine interval, the count moves little)
+                spec_key=(dev.index, C, width, height, channels, culled))
             if isinstance(lists, SpecLists):
                 # speculatively sized lists: the forward rasterizer is queued on them before the host has looked at
                 # this call's intersection count (include/gsplat_mi355x.h, "device-side n_isects")
