@@ -732,7 +732,7 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
                     raise
 
         prev = _spec_table().get(spec_key) if (spec_key is not None and SPECULATE_SIZES and POSTED_RESULTS
-                                               and want_order and C * N <= SPEC_MAX_ROWS) else None
+                                               and want_order and 0 < C * N <= SPEC_MAX_ROWS) else None
         if prev is not None and prev[0] > 0 and prev[1][0] == 0 and prev[1][FRONT_FROM_CLASS] == 0:
             capacity = int(prev[0] * SPEC_MARGIN) + 1024
             s_ids = torch.empty(capacity, device=dev, dtype=torch.int64) if want_ids else None
