@@ -167,7 +167,9 @@ def run_render(args, dev, rank, world):
 
     N, W, H, V = args.gaussians, args.width, args.height, args.views
     g = {k: v.to(dev) for k, v in synth_scene.make_gaussians(N, sh_degree=3, seed=42).items()}
-    cams = [synth_scene.make_cameras(1, W, H, frame=f % 120) for f in range(V)]
+    # (ego path x = -30 m ... +29.5 m: SURVEY.md 8(d)'s path from x = 0 leaves the +-40 m slab after frame 80, and a third
+    # of the views would render empty space -- 2750 instead of the honest figure below; --ego-x0 0 restores it)
+    cams = [synth_scene.make_cameras(1, W, H, frame=f % 120, origin_x=args.ego_x0) for f in range(V)]
     vm = torch.cat([c[0] for c in cams]).to(dev)
     Ks = torch.cat([c[1] for c in cams]).to(dev)
     out = [None]
@@ -180,6 +182,8 @@ def run_render(args, dev, rank, world):
 
     for _ in range(max(1, args.warmup)):
         views = step()
+    # views that show (nearly) nothing, from the warm-up pass's frames: a sanity figure for the trajectory
+    empty = int((out[0].reshape(out[0].shape[0], -1).float().mean(1) < 1.0).sum())
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -202,7 +206,8 @@ def run_render(args, dev, rank, world):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[4]: {N} Gaussians, SH deg 3, {V}-view {W}x{H} trajectory, packed, no "
                                    f"gradients, views sharded over {world} rank(s) ({len(views)} on rank 0), "
-                                   f"{args.views_per_call} views per call, uint8 frames copied to pinned host memory",
+                                   f"{args.views_per_call} views per call, uint8 frames copied to pinned host memory; ego "
+                                   f"path from x = {args.ego_x0} m, {empty} of rank 0's views empty",
                        "gaussians": N, "views": V, "width": W, "height": H,
                        "parallelism": f"view sharding x{world}, no collective" if world > 1 else "single GPU"}}),
               flush=True)
@@ -282,6 +287,8 @@ def main():
     ap.add_argument("--frames", type=int, default=120)
     ap.add_argument("--views", type=int, default=600)
     ap.add_argument("--views-per-call", type=int, default=4)
+    ap.add_argument("--ego-x0", type=float, default=-30.0,
+                    help="frames / render: x of the ego at frame 0 (the scene spans +-40 m, a 120-frame path is 60 m long)")
     ap.add_argument("--refine-interval", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=4)
@@ -389,7 +396,7 @@ def main():
 
         mine = shard_views(args.frames, rank, world)
         assert len(mine) > 0, "more ranks than frames"
-        cams = [synth_scene.make_cameras(C, W, H, frame=f) for f in mine]
+        cams = [synth_scene.make_cameras(C, W, H, frame=f, origin_x=args.ego_x0) for f in mine]
         cams = [(a.to(dev), b.to(dev)) for a, b in cams]
         dstate = DensifyState()
     else:

@@ -8,7 +8,7 @@ from gsplat.harness import render_trajectory
 dev = torch.device("cuda:0")
 N, W, H, V, WORLD = 6_000_000, 1920, 1080, 600, 8
 g = {k: v.to(dev) for k, v in synth_scene.make_gaussians(N, sh_degree=3).items()}
-cams = [synth_scene.make_cameras(1, W, H, frame=f % 120) for f in range(V)]
+cams = [synth_scene.make_cameras(1, W, H, frame=f % 120, origin_x=-30.0) for f in range(V)]
 vm = torch.cat([c[0] for c in cams]).to(dev); Ks = torch.cat([c[1] for c in cams]).to(dev)
 res = {}
 for vpc in (1, 3, 5):

@@ -60,13 +60,16 @@ def _look_at_c2w(eye, yaw_deg: float, pitch_deg: float) -> torch.Tensor:
 RIG = [(0.0, 0.0), (180.0, 0.0), (90.0, 0.0), (-60.0, 0.0), (30.0, 35.0)]
 
 
-def make_cameras(C: int, width: int, height: int, frame: int = 0, dtype=torch.float32):
-    """viewmats [C,4,4] (world->camera), Ks [C,3,3]; FOV 90 deg horizontally, pixel centres +0.5."""
+def make_cameras(C: int, width: int, height: int, frame: int = 0, dtype=torch.float32, origin_x: float = 0.0):
+    """viewmats [C,4,4] (world->camera), Ks [C,3,3]; FOV 90 deg horizontally, pixel centres +0.5.  The ego sits at
+    x = origin_x + 0.5 m * frame: with origin_x = 0 a 120-frame path ends at x = 59.5 m, 20 m outside
+    the +-40 m slab of `make_gaussians`, and the forward camera shows nothing from frame 80 on; trajectory workloads
+    start at origin_x = -30 so that every frame is inside the scene."""
     vms, Ks = [], []
     for c in range(C):
         yaw, pitch = RIG[c % len(RIG)]
         f = frame + c // len(RIG)
-        c2w = _look_at_c2w((0.5 * f, 0.0, 1.6), yaw, pitch)
+        c2w = _look_at_c2w((origin_x + 0.5 * f, 0.0, 1.6), yaw, pitch)
         vms.append(torch.linalg.inv(c2w))
         fx = width / 2.0
         Ks.append(torch.tensor([[fx, 0, width / 2.0], [0, fx, height / 2.0], [0, 0, 1.0]], dtype=torch.float64))

@@ -57,7 +57,7 @@ def test_config5_trajectory_at_full_size_views_spread_over_the_trajectory(gpu_de
     N, W, H = 6_000_000, 1920, 1080
     g = {k: v.to(dev) for k, v in synth_scene.make_gaussians(N, sh_degree=3, seed=42).items()}
     frames_of = [0, 17, 37, 59, 60, 83, 101, 119]
-    cams = [synth_scene.make_cameras(1, W, H, frame=f) for f in frames_of]
+    cams = [synth_scene.make_cameras(1, W, H, frame=f, origin_x=-30.0) for f in frames_of]  # (inside the +-40 m slab)
     vm = torch.cat([c[0] for c in cams]).to(dev)
     Ks = torch.cat([c[1] for c in cams]).to(dev)
     V = len(frames_of)
