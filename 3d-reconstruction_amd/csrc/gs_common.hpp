@@ -22,8 +22,9 @@
 // leaves its outputs in a state no later kernel faults on.  Host side: the entry points of the same family look at the
 // flag when they are called (a plain host load, no synchronisation) and return GS_ERR_CONTRACT once, clearing it;
 // gs_contract_status() reads it on demand.  NULL from gs_contract_flag_device() (allocation failed) = no reporting.
-int32_t* gs_contract_flag_device();   // device-visible address for kernel arguments
-int gs_contract_take();               // host: current code (0 = none), cleared by the read
+// (library-internal: not part of the C ABI)
+__attribute__((visibility("hidden"))) int32_t* gs_contract_flag_device();   // device-visible address for kernel arguments
+__attribute__((visibility("hidden"))) int gs_contract_take();               // host: current code (0 = none), cleared by the read
 
 namespace gs {
 

@@ -566,6 +566,13 @@ class SpecLists:
             self.isect_ids = self.isect_ids[:n] if self.isect_ids is not None else None
         return ok
 
+    def abandon(self) -> None:
+        """The caller failed before resolve(): the kernels that post into this thread's slot may still be in flight,
+        and their values must not land after the NEXT call has armed the slot."""
+        dev = self.offsets.device
+        with B.device_guard(dev):
+            B.lib().gs_stream_synchronize(B.stream_handle(dev))
+
     def redo(self):
         dev = self.flatten_ids.device
         if self.classes[0] > 0 and self.isect_ids is None:
@@ -735,17 +742,22 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
                                                and want_order and 0 < C * N <= SPEC_MAX_ROWS) else None
         if prev is not None and prev[0] > 0 and prev[1][0] == 0 and prev[1][FRONT_FROM_CLASS] == 0:
             capacity = int(prev[0] * SPEC_MARGIN) + 1024
-            s_ids = torch.empty(capacity, device=dev, dtype=torch.int64) if want_ids else None
-            s_fids = torch.empty(capacity, device=dev, dtype=torch.int32)
-            s_pairs = torch.empty(capacity, device=dev, dtype=torch.int64)
-            with B.device_guard(dev):
-                B.check(lib.gs_isect_bin_build_dev(C, N, tile_width, tile_height, n_slices, group, regions,
-                                                   B.ptr(vis_list), B.ptr(vis_cnt), B.ptr(vis_masks), B.ptr(table),
-                                                   B.ptr(offsets), capacity, B.ptr(total), B.ptr(order), B.ptr(n_long),
-                                                   B.ptr(s_pairs), B.ptr(s_ids), B.ptr(s_fids),
-                                                   B.ptr(counts) if STAGED_SCATTER else None, st),
-                        "gs_isect_bin_build_dev")
-
+            try:
+                s_ids = torch.empty(capacity, device=dev, dtype=torch.int64) if want_ids else None
+                s_fids = torch.empty(capacity, device=dev, dtype=torch.int32)
+                s_pairs = torch.empty(capacity, device=dev, dtype=torch.int64)
+                with B.device_guard(dev):
+                    B.check(lib.gs_isect_bin_build_dev(C, N, tile_width, tile_height, n_slices, group, regions,
+                                                       B.ptr(vis_list), B.ptr(vis_cnt), B.ptr(vis_masks), B.ptr(table),
+                                                       B.ptr(offsets), capacity, B.ptr(total), B.ptr(order),
+                                                       B.ptr(n_long), B.ptr(s_pairs), B.ptr(s_ids), B.ptr(s_fids),
+                                                       B.ptr(counts) if STAGED_SCATTER else None, st),
+                            "gs_isect_bin_build_dev")
+            except BaseException:
+                # (as above: the slot is armed and nobody will wait on it -- let the posting kernels finish first)
+                with B.device_guard(dev):
+                    lib.gs_stream_synchronize(st)
+                raise
             return SpecLists(capacity, total, s_ids, s_fids, offsets, order, wait_posted, _build_lists, spec_key)
         n_isects, classes = wait_posted()
         if spec_key is not None and classes is not None:
@@ -895,67 +907,72 @@ class _RasterizeSplats(torch.autograd.Function):
             isect_ids, flatten_ids = isect_tiles_from_splats(splats, tiles_per_gauss, TW, TH)
             offsets = isect_offset_encode(isect_ids, C, TW, TH)
             prepare_outputs()
-        bg = B.f32c(backgrounds) if backgrounds is not None else None
-        rc, ra, last_ids, final_T = out["rc"], out["ra"], out["last_ids"], out["final_T"]
-        n_isects = flatten_ids.numel()  # (speculative lists: their capacity, > 0, until `spec.resolve()` below)
-        ctx.v_splats, ctx.v_ready = out["v_splats"], None
-        if ctx.v_splats is not None and ctx.v_splats.numel() * 4 > SIDE_STREAM_MIN_BYTES:
-            # large record: zero it on a side stream, where the HBM-bound fill hides behind the issue-bound forward
-            # rasterizer (issued here, behind the intersection stage: in front of it, it doubles the count pass)
-            main, side = torch.cuda.current_stream(dev), B.side_stream(dev)
-            side.wait_stream(main)
-            with B.device_guard(dev):  # (raw stream handle: no torch stream-context switch on the host)
-                B.check(B.lib().gs_fill_zero(B.ptr(ctx.v_splats), ctx.v_splats.numel() * 4, side.cuda_stream),
-                        "gs_fill_zero")
-            ctx.v_ready = torch.cuda.Event()
-            ctx.v_ready.record(side)
-            # written on the side stream: if the graph is dropped without a backward, the allocator must not hand
-            # the block to a main-stream tensor while the fill is still pending
-            ctx.v_splats.record_stream(side)
-        # longest-first tile schedule: by list length now, by the walked length (written by the forward) for backward
-        n_tiles = C * TH * TW
-        work = None
-        if n_isects == 0:
-            order = None
-        if n_isects > 0 and n_tiles <= 131072:
-            work = torch.empty(n_tiles, device=dev, dtype=torch.int32) if ctx.needs_input_grad[0] else None
-        if n_isects > 0 and n_tiles <= 131072 and order is None:
-            order = torch.empty(n_tiles, device=dev, dtype=torch.int32)
-            with B.device_guard(dev), B.timed("gs_raster_tile_order", dev):
-                B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, None, B.ptr(order), None,
-                                                     B.stream_handle(dev)), "gs_raster_tile_order")
-        geom = (C, N, width, height, tile_size, channels, ed)
-        if spec is not None:
-            with B.device_guard(dev):
-                status = B.lib().gs_rasterize_fwd_dev(C, width, height, tile_size, channels, B.ptr(splats),
-                                                      B.ptr(offsets), B.ptr(flatten_ids), spec.capacity,
-                                                      B.ptr(spec.total), B.ptr(bg), int(ed), B.ptr(rc), B.ptr(ra),
-                                                      B.ptr(last_ids), B.ptr(order), B.ptr(work), None, N,
-                                                      B.ptr(final_T), B.stream_handle(dev))
-            # GS_ERR_CONTRACT here: a speculative sort launch has already met a list beyond its buffer (a tile list
-            # above 6144 entries without the key array as scratch) -- a failed speculation, which resolve() reports too
-            # (size class 0 is not empty), not an error of this call
-            if status != B.GS_ERR_CONTRACT:
-                B.check(status, "gs_rasterize_fwd_dev")
-            if spec.resolve() and status == 0:
-                isect_ids, flatten_ids = spec.isect_ids, spec.flatten_ids
+        try:
+            bg = B.f32c(backgrounds) if backgrounds is not None else None
+            rc, ra, last_ids, final_T = out["rc"], out["ra"], out["last_ids"], out["final_T"]
+            n_isects = flatten_ids.numel()  # (speculative lists: their capacity, > 0, until `spec.resolve()` below)
+            ctx.v_splats, ctx.v_ready = out["v_splats"], None
+            if ctx.v_splats is not None and ctx.v_splats.numel() * 4 > SIDE_STREAM_MIN_BYTES:
+                # large record: zero it on a side stream, where the HBM-bound fill hides behind the issue-bound forward
+                # rasterizer (issued here, behind the intersection stage: in front of it, it doubles the count pass)
+                main, side = torch.cuda.current_stream(dev), B.side_stream(dev)
+                side.wait_stream(main)
+                with B.device_guard(dev):  # (raw stream handle: no torch stream-context switch on the host)
+                    B.check(B.lib().gs_fill_zero(B.ptr(ctx.v_splats), ctx.v_splats.numel() * 4, side.cuda_stream),
+                            "gs_fill_zero")
+                ctx.v_ready = torch.cuda.Event()
+                ctx.v_ready.record(side)
+                # written on the side stream: if the graph is dropped without a backward, the allocator must not hand
+                # the block to a main-stream tensor while the fill is still pending
+                ctx.v_splats.record_stream(side)
+            # longest-first tile schedule: by list length now, by the walked length (written by the forward) for backward
+            n_tiles = C * TH * TW
+            work = None
+            if n_isects == 0:
+                order = None
+            if n_isects > 0 and n_tiles <= 131072:
+                work = torch.empty(n_tiles, device=dev, dtype=torch.int32) if ctx.needs_input_grad[0] else None
+            if n_isects > 0 and n_tiles <= 131072 and order is None:
+                order = torch.empty(n_tiles, device=dev, dtype=torch.int32)
+                with B.device_guard(dev), B.timed("gs_raster_tile_order", dev):
+                    B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, None, B.ptr(order), None,
+                                                         B.stream_handle(dev)), "gs_raster_tile_order")
+            geom = (C, N, width, height, tile_size, channels, ed)
+            if spec is not None:
+                with B.device_guard(dev):
+                    status = B.lib().gs_rasterize_fwd_dev(C, width, height, tile_size, channels, B.ptr(splats),
+                                                          B.ptr(offsets), B.ptr(flatten_ids), spec.capacity,
+                                                          B.ptr(spec.total), B.ptr(bg), int(ed), B.ptr(rc), B.ptr(ra),
+                                                          B.ptr(last_ids), B.ptr(order), B.ptr(work), None, N,
+                                                          B.ptr(final_T), B.stream_handle(dev))
+                # GS_ERR_CONTRACT here: a speculative sort launch has already met a list beyond its buffer (a tile list
+                # above 6144 entries without the key array as scratch) -- a failed speculation, which resolve() reports too
+                # (size class 0 is not empty), not an error of this call
+                if status != B.GS_ERR_CONTRACT:
+                    B.check(status, "gs_rasterize_fwd_dev")
+                if spec.resolve() and status == 0:
+                    isect_ids, flatten_ids = spec.isect_ids, spec.flatten_ids
+                else:
+                    # the count did not fit the capacity (or a list was too long for the speculative sort): nothing was
+                    # written; the same launches again on lists of the exact size
+                    isect_ids, flatten_ids, offsets, order, fs = spec.redo()
+                    if flatten_ids.numel() == 0:
+                        order = work = None
+                    elif order is None and n_tiles <= 131072:
+                        order = torch.empty(n_tiles, device=dev, dtype=torch.int32)
+                        with B.device_guard(dev):
+                            B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), flatten_ids.numel(), None,
+                                                                 B.ptr(order), None, B.stream_handle(dev)),
+                                    "gs_raster_tile_order")
+                    launch_raster_fwd(splats, offsets, flatten_ids, order, fs, bg, geom, rc, ra, last_ids, work, None,
+                                      final_T)
+                n_isects = flatten_ids.numel()
             else:
-                # the count did not fit the capacity (or a list was too long for the speculative sort): nothing was
-                # written; the same launches again on lists of the exact size
-                isect_ids, flatten_ids, offsets, order, fs = spec.redo()
-                if flatten_ids.numel() == 0:
-                    order = work = None
-                elif order is None and n_tiles <= 131072:
-                    order = torch.empty(n_tiles, device=dev, dtype=torch.int32)
-                    with B.device_guard(dev):
-                        B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), flatten_ids.numel(), None,
-                                                             B.ptr(order), None, B.stream_handle(dev)),
-                                "gs_raster_tile_order")
-                launch_raster_fwd(splats, offsets, flatten_ids, order, fs, bg, geom, rc, ra, last_ids, work, None,
-                                  final_T)
-            n_isects = flatten_ids.numel()
-        else:
-            launch_raster_fwd(splats, offsets, flatten_ids, order, fs, bg, geom, rc, ra, last_ids, work, None, final_T)
+                launch_raster_fwd(splats, offsets, flatten_ids, order, fs, bg, geom, rc, ra, last_ids, work, None, final_T)
+        except BaseException:
+            if spec is not None and spec.n_isects is None:  # (failed before the posted count was consumed)
+                spec.abandon()
+            raise
         _tls.front_sort = fs
         _tls.last_tile_work = work  # (diagnostics: bench.py sums it into the list entries the backward walks)
         _tls.raster_state = (splats, offsets, isect_ids, flatten_ids, order, fs)  # handed to rasterization() for the lazy completion of meta["isect_ids"/"flatten_ids"]
