@@ -120,8 +120,9 @@ def measured_issue(kernel):
             "kernel_cycles": k.get("kernel_cycles"), "vgprs": k.get("vgprs"),
             "lds_bank_conflict_rate": k.get("lds_bank_conflict_rate"), "atomic_GBps": k.get("atomic_GBps"),
             "atomic_frac_of_peak": k.get("atomic_frac_of_1300GBps"),
-            "source": "profiles/issue.json (rocprofv3 --pmc SQ_ACTIVE_INST_VALU, SQ_BUSY_CYCLES, SQ_LDS_BANK_CONFLICT, "
-                      "TCC_EA0_ATOMIC over this command)"}
+            "source": "profiles/issue.json (profiles/pmc_issue.py: rocprofv3 --pmc SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, "
+                      "SQ_BUSY_CYCLES, SQ_LDS_BANK_CONFLICT, TCC_EA0_ATOMIC over this command; instruction mix and VGPRs "
+                      "from the kernel's ISA, profiles/isa_mix.py)"}
 
 
 def cpu_baseline(threads: int):
