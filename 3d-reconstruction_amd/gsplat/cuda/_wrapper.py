@@ -779,7 +779,10 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
             while_counting()
         n_isects = int(total.item())  # the one host sync of the pipeline (gsplat has the same one)
         return _build_lists(n_isects, n_long.tolist() if want_order else None)
+
+
 def isect_offset_encode(isect_ids: Tensor, n_cameras: int, tile_width: int, tile_height: int) -> Tensor:
+    """Appendix A.4: offsets [C,tile_h,tile_w] int32 = lower bound of every (camera, tile) in the sorted keys."""
     dev = B.require_gpu(isect_ids)
     offsets = torch.empty(n_cameras, tile_height, tile_width, device=dev, dtype=torch.int32)
     with B.device_guard(dev), B.timed("gs_isect_offset_encode", dev):
@@ -1057,3 +1060,191 @@ class _RasterizeSplats(torch.autograd.Function):
                 vc[..., -1] = vc[..., -1] / ra[..., 0].clamp(min=1e-10)
             v_bg = (vc * (1.0 - ra)).sum(dim=(1, 2))
         return v_splats, v_means2d, None, v_bg, None, None, None, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------- gsplat's stage-level functions
+# `rasterization()` above runs the stages fused (one record per splat, lists built inside the rasterize op).  gsplat also
+# exports the stages one by one (gsplat/cuda/_wrapper.py of gsplat 1.x: fully_fused_projection, isect_tiles,
+# isect_offset_encode, rasterize_to_pixels); code that drives them itself -- gsplat's own tests do -- finds them here
+# with the same signatures, on the same kernels.  They are the general route, not the fast one: each validates its
+# integer inputs on the host before a kernel indexes with them.
+def fully_fused_projection(means: Tensor, covars: Optional[Tensor], quats: Optional[Tensor], scales: Optional[Tensor],
+                           viewmats: Tensor, Ks: Tensor, width: int, height: int, eps2d: float = 0.3,
+                           near_plane: float = 0.01, far_plane: float = 1e10, radius_clip: float = 0.0,
+                           packed: bool = False, sparse_grad: bool = False, calc_compensations: bool = False):
+    """Appendix A.1: -> (radii [C,N] int32, means2d [C,N,2], depths [C,N], conics [C,N,3],
+    compensations [C,N] or None).  Rows with radii == 0 are zero in every output.  Differentiable in means, covars or
+    quats/scales, and viewmats."""
+    if packed or sparse_grad:
+        raise NotImplementedError("gsplat (MI355X build): fully_fused_projection(packed=True) -- use rasterization(packed=True)")
+    assert (covars is not None) or (quats is not None and scales is not None), "covars or quats+scales"
+    N, C = means.shape[0], viewmats.shape[0]
+    if covars is not None and covars.dim() == 3:  # gsplat takes [N,3,3] too
+        covars = torch.stack([covars[:, 0, 0], covars[:, 0, 1], covars[:, 0, 2], covars[:, 1, 1], covars[:, 1, 2],
+                              covars[:, 2, 2]], dim=-1)
+    # no colours, the depth in the first colour slot, opacity 1: record[5] is then the compensation itself
+    params = _make_params(N, C, int(width), int(height), 16, eps2d, near_plane, far_plane, radius_clip,
+                          calc_compensations, B.GS_COLOR_NONE, 0, None, 0, True)
+    ones = torch.ones(N, device=means.device, dtype=torch.float32)
+    splats, means2d, radii, _tiles = _ProjectSplats.apply(means, quats, scales, ones, None, viewmats, Ks, None, params,
+                                                          covars)
+    vis = radii > 0
+    zero = torch.zeros((), device=means.device, dtype=torch.float32)
+    depths = torch.where(vis, splats[..., 6], zero)
+    conics = torch.where(vis[..., None], splats[..., 2:5], zero)
+    comps = torch.where(vis, splats[..., 5], zero) if calc_compensations else None
+    return radii, means2d, depths, conics, comps
+
+
+def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, tile_width: int, tile_height: int,
+                sort: bool = True, packed: bool = False, n_cameras: Optional[int] = None,
+                camera_ids: Optional[Tensor] = None, gaussian_ids: Optional[Tensor] = None):
+    """Appendix A.3: -> (tiles_per_gauss [C,N] int32, isect_ids [I] int64, flatten_ids [I] int32).  Any tile_size.
+    The tile boxes are computed here in fp32 exactly as the projection kernel does it, then emitted and sorted by the
+    kernels of `isect_tiles_from_splats`."""
+    if packed:
+        raise NotImplementedError("gsplat (MI355X build): isect_tiles(packed=True) -- use rasterization(packed=True)")
+    dev = B.require_gpu(means2d, radii, depths)
+    C, N = radii.shape
+    assert means2d.shape == (C, N, 2) and depths.shape == (C, N), (means2d.shape, depths.shape)
+    assert 0 < tile_width <= 0xFFFF and 0 < tile_height <= 0xFFFF
+    with torch.no_grad():
+        ts = float(tile_size)
+        m = means2d.detach().to(torch.float32) / ts
+        tr = radii.to(torch.float32) / ts
+        x0 = torch.floor(m[..., 0] - tr).clamp(0, tile_width)
+        x1 = torch.ceil(m[..., 0] + tr).clamp(0, tile_width)
+        y0 = torch.floor(m[..., 1] - tr).clamp(0, tile_height)
+        y1 = torch.ceil(m[..., 1] + tr).clamp(0, tile_height)
+        box = torch.stack([x0, x1, y0, y1], dim=-1)
+        ok = (radii > 0) & torch.isfinite(box).all(dim=-1)  # (a NaN mean gives no tiles: the kernel's float->int is 0 too)
+        x0, x1, y0, y1 = (torch.where(ok, v, torch.zeros_like(v)).to(torch.int32) for v in (x0, x1, y0, y1))
+        tiles = ((y1 - y0) * (x1 - x0)).contiguous()
+        rec = torch.zeros(C, N, B.GS_REC, device=dev, dtype=torch.float32)
+        rec[..., 10] = depths.detach().to(torch.float32)
+        bits = rec.view(torch.int32)
+        bits[..., 13] = x0 | (y0 << 16)
+        bits[..., 14] = x1 | (y1 << 16)
+        isect_ids, flatten_ids = isect_tiles_from_splats(rec, tiles, tile_width, tile_height, sort=sort)
+    return tiles, isect_ids, flatten_ids
+
+
+class _RasterizeLists(torch.autograd.Function):
+    """records [R,16] + caller-supplied tile lists -> (render_colors, render_alphas); `channels` <= 4."""
+
+    @staticmethod
+    def forward(ctx, records, means2d, offsets, flatten_ids, backgrounds, width, height, channels, absgrad):
+        dev = B.require_gpu(records, offsets, flatten_ids)
+        C, TH, TW = offsets.shape
+        n_isects, n_tiles = flatten_ids.numel(), C * TH * TW
+        records = B.f32c(records)
+        bg = B.f32c(backgrounds) if backgrounds is not None else None
+        want_grad = ctx.needs_input_grad[0]
+        rc = torch.empty(C, height, width, channels, device=dev, dtype=torch.float32)
+        ra = torch.empty(C, height, width, 1, device=dev, dtype=torch.float32)
+        last_ids = torch.empty(C, height, width, device=dev, dtype=torch.int32)
+        final_T = torch.empty(C, height, width, device=dev, dtype=torch.float32) if want_grad else None
+        order = None
+        if n_isects > 0 and n_tiles <= 131072:
+            order = torch.empty(n_tiles, device=dev, dtype=torch.int32)
+            with B.device_guard(dev):
+                B.check(B.lib().gs_raster_tile_order(n_tiles, B.ptr(offsets), n_isects, None, B.ptr(order), None,
+                                                     B.stream_handle(dev)), "gs_raster_tile_order")
+        geom = (C, records.shape[0], width, height, 16, channels, False)
+        launch_raster_fwd(records, offsets, flatten_ids, order, None, bg, geom, rc, ra, last_ids, None, None, final_T)
+        ctx.geom = (C, width, height, channels, absgrad)
+        ctx.has_bg, ctx.has_final_T = bg is not None, final_T is not None
+        empty = torch.empty(0, device=dev)
+        ctx.save_for_backward(records, means2d, offsets, flatten_ids, bg if bg is not None else empty, rc, ra, last_ids,
+                              final_T if final_T is not None else empty, order if order is not None else empty)
+        ctx.has_order = order is not None
+        return rc, ra
+
+    @staticmethod
+    def backward(ctx, v_rc, v_ra):
+        records, means2d, offsets, flatten_ids, bg, rc, ra, last_ids, final_T, order = ctx.saved_tensors
+        C, width, height, channels, absgrad = ctx.geom
+        dev = records.device
+        v_rc = B.f32c(v_rc) if v_rc is not None else torch.zeros_like(rc)
+        v_ra = B.f32c(v_ra) if v_ra is not None else torch.zeros_like(ra)
+        v_records = torch.zeros_like(records)
+        if flatten_ids.numel() > 0:
+            with B.device_guard(dev), B.timed("gs_rasterize_bwd", dev):
+                B.check(B.lib().gs_rasterize_bwd(C, width, height, 16, channels, B.ptr(records), B.ptr(offsets),
+                                                 B.ptr(flatten_ids), flatten_ids.numel(),
+                                                 B.ptr(bg) if ctx.has_bg else None, 0, B.ptr(rc), B.ptr(ra),
+                                                 B.ptr(last_ids), B.ptr(v_rc), B.ptr(v_ra), int(absgrad is not None),
+                                                 B.ptr(v_records), B.ptr(order) if ctx.has_order else None,
+                                                 B.ptr(final_T) if ctx.has_final_T else None, B.stream_handle(dev)),
+                        "gs_rasterize_bwd")
+        if absgrad is not None:
+            # (pass id, state shared by the passes of one rasterize_to_pixels call): above four channels the attribute
+            # is the SUM of the passes' abs-gradients, as in rasterization()'s >4-channel path (set_absgrad_accumulate)
+            pass_id, acc = absgrad
+            if pass_id in acc["seen"]:  # a second backward through the same graph starts over
+                acc["seen"], acc["sum"] = set(), None
+            ag = v_records[:, 10:12].reshape(means2d.shape)
+            acc["sum"] = ag if acc["sum"] is None else acc["sum"] + ag
+            acc["seen"].add(pass_id)
+            means2d.absgrad = acc["sum"]
+        v_bg = (v_rc * (1.0 - ra)).sum(dim=(1, 2)) if (ctx.has_bg and ctx.needs_input_grad[4]) else None
+        return v_records, None, None, None, v_bg, None, None, None, None
+
+
+def rasterize_to_pixels(means2d: Tensor, conics: Tensor, colors: Tensor, opacities: Tensor, image_width: int,
+                        image_height: int, tile_size: int, isect_offsets: Tensor, flatten_ids: Tensor,
+                        backgrounds: Optional[Tensor] = None, masks: Optional[Tensor] = None, packed: bool = False,
+                        absgrad: bool = False):
+    """Appendix A.5 / A.6: -> (render_colors [C,H,W,D], render_alphas [C,H,W,1]).  Dense ([C,N,*]) or packed ([nnz,*])
+    operands; any channel count (passes of four; `means2d.absgrad` is then the sum of the passes' abs-gradients, an upper
+    bound of the one-kernel value); `masks` [C,tile_h,tile_w] (False: the tile shows the background, alpha 0).
+    `flatten_ids` and `isect_offsets` are checked on the host (one synchronisation) before the kernels index with them."""
+    if int(tile_size) != 16:
+        raise NotImplementedError("gsplat (MI355X build): tile_size must be 16")
+    dev = B.require_gpu(means2d, conics, colors, opacities, isect_offsets, flatten_ids)
+    C, TH, TW = isect_offsets.shape
+    width, height = int(image_width), int(image_height)
+    assert TH == math.ceil(height / 16) and TW == math.ceil(width / 16), (isect_offsets.shape, width, height)
+    if packed:
+        R = means2d.shape[0]
+        assert means2d.shape == (R, 2) and conics.shape == (R, 3) and opacities.shape == (R,) and colors.shape[0] == R
+    else:
+        assert means2d.dim() == 3 and means2d.shape[0] == C, means2d.shape
+        R = C * means2d.shape[1]
+        assert conics.shape == means2d.shape[:2] + (3,) and opacities.shape == means2d.shape[:2]
+        assert colors.shape[:2] == means2d.shape[:2]
+    D = colors.shape[-1]
+    assert D >= 1 and (backgrounds is None or backgrounds.shape == (C, D))
+    assert isect_offsets.dtype == torch.int32 and flatten_ids.dtype == torch.int32 and flatten_ids.dim() == 1
+    isect_offsets, flatten_ids = isect_offsets.contiguous(), flatten_ids.contiguous()
+    n_isects = flatten_ids.numel()
+    # the kernels gather records through these: out-of-range values are a memory fault, not an exception
+    off = isect_offsets.reshape(-1)
+    bad = (off[0] != 0) | (off[1:] < off[:-1]).any() | (off[-1] > n_isects)
+    if n_isects > 0:
+        bad = bad | (flatten_ids.min() < 0) | (flatten_ids.max() >= R)
+    if bool(bad):
+        raise ValueError("rasterize_to_pixels: isect_offsets must start at 0, be non-decreasing and stay within "
+                         "len(flatten_ids); flatten_ids must lie in [0, rows)")
+    m2 = means2d.reshape(R, 2).to(torch.float32)
+    head = torch.cat([m2, conics.reshape(R, 3).to(torch.float32), opacities.reshape(R, 1).to(torch.float32)], dim=-1)
+    cols = colors.reshape(R, D).to(torch.float32)
+    outs, alphas = [], None
+    acc = {"seen": set(), "sum": None} if absgrad else None
+    for c0 in range(0, D, 4):
+        ch = min(4, D - c0)
+        rec = torch.cat([head, cols[:, c0:c0 + ch], head.new_zeros(R, B.GS_REC - 6 - ch)], dim=-1)
+        bg = backgrounds[:, c0:c0 + ch] if backgrounds is not None else None
+        rc, ra = _RasterizeLists.apply(rec, means2d, isect_offsets, flatten_ids, bg, width, height, ch,
+                                       (c0, acc) if absgrad else None)
+        outs.append(rc)
+        alphas = ra if alphas is None else alphas
+    render_colors = outs[0] if len(outs) == 1 else torch.cat(outs, dim=-1)
+    if masks is not None:
+        assert masks.shape == (C, TH, TW)
+        pix = masks.to(torch.bool).repeat_interleave(16, dim=1).repeat_interleave(16, dim=2)[:, :height, :width, None]
+        fill = (backgrounds[:, None, None, :].expand_as(render_colors) if backgrounds is not None
+                else torch.zeros_like(render_colors))
+        render_colors = torch.where(pix, render_colors, fill)
+        alphas = torch.where(pix, alphas, torch.zeros_like(alphas))
+    return render_colors, alphas

@@ -69,6 +69,40 @@ def test_reference_import_paths_exist():
         assert sig.parameters[kw].default == default, kw
 
 
+def test_stage_level_functions_have_gsplat_signatures_and_no_cpu_path():
+    """gsplat 1.x's gsplat/cuda/_wrapper.py: the positional parameters and defaults of the four stage functions."""
+    import inspect
+    import gsplat
+
+    want = {
+        "fully_fused_projection": (["means", "covars", "quats", "scales", "viewmats", "Ks", "width", "height"],
+                                   dict(eps2d=0.3, near_plane=0.01, far_plane=1e10, radius_clip=0.0, packed=False,
+                                        sparse_grad=False, calc_compensations=False)),
+        "isect_tiles": (["means2d", "radii", "depths", "tile_size", "tile_width", "tile_height"],
+                        dict(sort=True, packed=False, n_cameras=None, camera_ids=None, gaussian_ids=None)),
+        "isect_offset_encode": (["isect_ids", "n_cameras", "tile_width", "tile_height"], {}),
+        "rasterize_to_pixels": (["means2d", "conics", "colors", "opacities", "image_width", "image_height", "tile_size",
+                                 "isect_offsets", "flatten_ids"],
+                                dict(backgrounds=None, masks=None, packed=False, absgrad=False)),
+    }
+    for name, (positional, defaults) in want.items():
+        fn = getattr(gsplat, name)
+        assert fn is getattr(gsplat.cuda._wrapper, name)
+        sig = inspect.signature(fn)
+        assert list(sig.parameters)[:len(positional)] == positional, name
+        for kw, default in defaults.items():
+            assert sig.parameters[kw].default == default, (name, kw)
+    z = lambda *s: torch.zeros(*s)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        gsplat.fully_fused_projection(z(4, 3), None, z(4, 4), z(4, 3), z(1, 4, 4), z(1, 3, 3), 32, 32)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        gsplat.isect_tiles(z(1, 4, 2), z(1, 4).int(), z(1, 4), 16, 2, 2)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        gsplat.rasterize_to_pixels(z(1, 4, 2), z(1, 4, 3), z(1, 4, 3), z(1, 4), 32, 32, 16, z(1, 2, 2).int(), z(0).int())
+    with pytest.raises(NotImplementedError):
+        gsplat.fully_fused_projection(z(4, 3), None, z(4, 4), z(4, 3), z(1, 4, 4), z(1, 3, 3), 32, 32, packed=True)
+
+
 def test_no_cpu_fallback_and_shape_errors():
     from gsplat.rendering import rasterization
     from gsplat.cuda._wrapper import spherical_harmonics
