@@ -1074,9 +1074,20 @@ def fully_fused_projection(means: Tensor, covars: Optional[Tensor], quats: Optio
                            packed: bool = False, sparse_grad: bool = False, calc_compensations: bool = False):
     """Appendix A.1: -> (radii [C,N] int32, means2d [C,N,2], depths [C,N], conics [C,N,3],
     compensations [C,N] or None).  Rows with radii == 0 are zero in every output.  Differentiable in means, covars or
-    quats/scales, and viewmats."""
-    if packed or sparse_grad:
-        raise NotImplementedError("gsplat (MI355X build): fully_fused_projection(packed=True) -- use rasterization(packed=True)")
+    quats/scales, and viewmats.
+    packed=True (A.7): -> (camera_ids [nnz] int64, gaussian_ids [nnz] int64, radii [nnz], means2d [nnz,2], depths [nnz],
+    conics [nnz,3], compensations [nnz] or None), the visible rows in ascending (camera, Gaussian) order; a gather of the
+    dense outputs (one host synchronisation for nnz), so gradients flow as in the dense form."""
+    if sparse_grad:
+        raise NotImplementedError("gsplat (MI355X build): sparse_grad is not supported (the reference never sets it)")
+    if packed:
+        radii, means2d, depths, conics, comps = fully_fused_projection(
+            means, covars, quats, scales, viewmats, Ks, width, height, eps2d, near_plane, far_plane, radius_clip, False,
+            False, calc_compensations)
+        camera_ids, gaussian_ids = torch.nonzero(radii > 0, as_tuple=True)
+        return (camera_ids, gaussian_ids, radii[camera_ids, gaussian_ids], means2d[camera_ids, gaussian_ids],
+                depths[camera_ids, gaussian_ids], conics[camera_ids, gaussian_ids],
+                comps[camera_ids, gaussian_ids] if comps is not None else None)
     assert (covars is not None) or (quats is not None and scales is not None), "covars or quats+scales"
     N, C = means.shape[0], viewmats.shape[0]
     if covars is not None and covars.dim() == 3:  # gsplat takes [N,3,3] too
@@ -1101,9 +1112,37 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
                 camera_ids: Optional[Tensor] = None, gaussian_ids: Optional[Tensor] = None):
     """Appendix A.3: -> (tiles_per_gauss [C,N] int32, isect_ids [I] int64, flatten_ids [I] int32).  Any tile_size.
     The tile boxes are computed here in fp32 exactly as the projection kernel does it, then emitted and sorted by the
-    kernels of `isect_tiles_from_splats`."""
+    kernels of `isect_tiles_from_splats`.
+    packed=True (A.7): means2d [nnz,2], radii [nnz], depths [nnz] with `n_cameras` and `camera_ids` [nnz] (gaussian_ids
+    is not needed); tiles_per_gauss is [nnz] and flatten_ids index the packed rows.  Ties in (camera, tile, depth) come
+    out in ascending packed row, as gsplat's stable sort of its emission order leaves them."""
     if packed:
-        raise NotImplementedError("gsplat (MI355X build): isect_tiles(packed=True) -- use rasterization(packed=True)")
+        assert n_cameras is not None and camera_ids is not None, "packed=True needs n_cameras and camera_ids"
+        dev = B.require_gpu(means2d, radii, depths, camera_ids)
+        nnz, C = radii.shape[0], int(n_cameras)
+        assert means2d.shape == (nnz, 2) and depths.shape == (nnz,) and camera_ids.shape == (nnz,)
+        empty = lambda dt: torch.empty(0, device=dev, dtype=dt)
+        if nnz == 0:
+            return empty(torch.int32), empty(torch.int64), empty(torch.int32)
+        cam = camera_ids.long()
+        if bool(((cam < 0) | (cam >= C)).any()):
+            raise ValueError("isect_tiles: camera_ids must lie in [0, n_cameras)")
+        # packed row r of camera c sits at column r of camera c's row of a [C, nnz] layout (every other cell holds no
+        # tiles): the kernels' flat id c * nnz + r gives the camera by division and the packed row by remainder, and
+        # ascending flat id within a camera is ascending packed row
+        rows = torch.arange(nnz, device=dev)
+        m_d = torch.zeros(C, nnz, 2, device=dev, dtype=torch.float32)
+        r_d = torch.zeros(C, nnz, device=dev, dtype=torch.int32)
+        d_d = torch.zeros(C, nnz, device=dev, dtype=torch.float32)
+        m_d[cam, rows] = means2d.detach().to(torch.float32)
+        r_d[cam, rows] = radii.to(torch.int32)
+        d_d[cam, rows] = depths.detach().to(torch.float32)
+        tiles, isect_ids, fids = isect_tiles(m_d, r_d, d_d, tile_size, tile_width, tile_height, sort=sort)
+        flatten_ids = (fids % nnz).to(torch.int32)
+        if not sort:  # gsplat emits in packed-row order whatever the camera
+            order = torch.sort(flatten_ids.long(), stable=True).indices
+            isect_ids, flatten_ids = isect_ids[order], flatten_ids[order]
+        return tiles[cam, rows].contiguous(), isect_ids, flatten_ids
     dev = B.require_gpu(means2d, radii, depths)
     C, N = radii.shape
     assert means2d.shape == (C, N, 2) and depths.shape == (C, N), (means2d.shape, depths.shape)

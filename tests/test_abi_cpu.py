@@ -100,7 +100,7 @@ def test_stage_level_functions_have_gsplat_signatures_and_no_cpu_path():
     with pytest.raises(RuntimeError, match="no CPU path"):
         gsplat.rasterize_to_pixels(z(1, 4, 2), z(1, 4, 3), z(1, 4, 3), z(1, 4), 32, 32, 16, z(1, 2, 2).int(), z(0).int())
     with pytest.raises(NotImplementedError):
-        gsplat.fully_fused_projection(z(4, 3), None, z(4, 4), z(4, 3), z(1, 4, 4), z(1, 3, 3), 32, 32, packed=True)
+        gsplat.fully_fused_projection(z(4, 3), None, z(4, 4), z(4, 3), z(1, 4, 4), z(1, 3, 3), 32, 32, sparse_grad=True)
 
 
 def test_no_cpu_fallback_and_shape_errors():

@@ -269,3 +269,75 @@ def test_stage_chain_equals_rasterization(gpu_device):
                                         gg["opacities"][None].expand(C, N), W, H, 16, offs, fids)
     assert_close("chain.colors", rc, rc_f, atol=1e-6, rtol=1e-6)
     assert_close("chain.alphas", ra, ra_f, atol=1e-6, rtol=1e-6)
+
+
+def test_packed_stage_chain_equals_the_dense_one(gpu_device):
+    """gsplat's packed forms (A.7): fully_fused_projection(packed=True) -> isect_tiles(packed=True, n_cameras,
+    camera_ids) -> isect_offset_encode -> rasterize_to_pixels(packed=True).  Integer outputs against the oracle's dense
+    lists renumbered onto the visible rows, bit for bit; images bit-equal to the dense chain's; gradients of the
+    Gaussian parameters equal to the dense chain's up to the order of the backward's float atomics."""
+    import gsplat
+
+    dev = gpu_device
+    W, H, C, N, D = 150, 70, 3, 4000, 3
+    g, vm, Ks = _scene(N, C, W, H, seed=21)
+    gg = to_dev(g, dev)
+    TW, TH = math.ceil(W / 16), math.ceil(H / 16)
+    colors = gg["colors"][None].expand(C, N, D).contiguous()
+    opac = gg["opacities"][None].expand(C, N).contiguous()
+    bg = torch.rand(C, D, device=dev)
+    torch.manual_seed(2)
+    wc, wa = torch.randn(C, H, W, D, device=dev), torch.randn(C, H, W, 1, device=dev)
+
+    def run(packed):
+        leaves = {k: gg[k].detach().clone().requires_grad_(True) for k in ("means", "quats", "scales")}
+        vmg = vm.to(dev).requires_grad_(True)
+        out = gsplat.fully_fused_projection(leaves["means"], None, leaves["quats"], leaves["scales"], vmg, Ks.to(dev),
+                                            W, H, near_plane=0.1, packed=packed, calc_compensations=True)
+        if packed:
+            cam, gau, radii, m2, dep, con, comp = out
+            tiles, ids, fids = gsplat.isect_tiles(m2, radii, dep, 16, TW, TH, packed=True, n_cameras=C,
+                                                  camera_ids=cam, gaussian_ids=gau)
+            col, op = colors[cam, gau], opac[cam, gau] * comp
+        else:
+            radii, m2, dep, con, comp = out
+            tiles, ids, fids = gsplat.isect_tiles(m2, radii, dep, 16, TW, TH)
+            col, op = colors, opac * comp
+        offs = gsplat.isect_offset_encode(ids, C, TW, TH)
+        rc, ra = gsplat.rasterize_to_pixels(m2, con, col, op, W, H, 16, offs, fids, backgrounds=bg, packed=packed)
+        ((rc * wc).sum() + (ra * wa).sum()).backward()
+        grads = {k: v.grad for k, v in leaves.items()}
+        grads["viewmats"] = vmg.grad
+        return out, tiles, ids, fids, offs, rc, ra, grads
+
+    out_p, tiles_p, ids_p, fids_p, offs_p, rc_p, ra_p, g_p = run(True)
+    out_d, tiles_d, ids_d, fids_d, offs_d, rc_d, ra_d, g_d = run(False)
+    cam, gau = out_p[0], out_p[1]
+    radii_d = out_d[0]
+    vis = radii_d > 0
+    assert cam.dtype == torch.int64 and gau.dtype == torch.int64
+    assert torch.equal(torch.stack([cam, gau], 1), torch.nonzero(vis))  # ascending (camera, Gaussian)
+    for a, b in zip(out_p[2:], out_d):
+        assert torch.equal(a, b[cam, gau])
+    assert torch.equal(tiles_p, tiles_d[cam, gau]) and torch.equal(ids_p, ids_d) and torch.equal(offs_p, offs_d)
+    renum = torch.full((C * N,), -1, device=dev, dtype=torch.int32)
+    renum[cam * N + gau] = torch.arange(cam.numel(), device=dev, dtype=torch.int32)
+    assert torch.equal(fids_p, renum[fids_d.long()])
+    # ... and against the oracle fed the same fp32 stage outputs
+    t_o, i_o, f_o = oracle.isect_tiles(out_d[1].detach().cpu(), radii_d.cpu(), out_d[2].detach().cpu(), 16, TW, TH)
+    assert torch.equal(ids_p.cpu(), i_o) and torch.equal(fids_p.cpu(), renum.cpu()[f_o.long()])
+    assert torch.equal(tiles_p.cpu(), t_o[cam.cpu(), gau.cpu()])
+    assert torch.equal(rc_p, rc_d) and torch.equal(ra_p, ra_d)
+    assert int(vis.sum()) > 1000
+    for k in g_d:
+        assert_close(f"packed-chain.v_{k}", g_p[k], g_d[k], max_bad_frac=1e-3, max_rel_l2=1e-4, scale_atol=True)
+    # sort=False emits in packed-row order; camera ids out of range are rejected on the host
+    _, ids_u, fids_u = gsplat.isect_tiles(out_p[3].detach(), out_p[2], out_p[4].detach(), 16, TW, TH, sort=False,
+                                          packed=True, n_cameras=C, camera_ids=cam)
+    assert bool((fids_u[1:] >= fids_u[:-1]).all()) and torch.equal(ids_u.sort().values, ids_p)
+    with pytest.raises(ValueError):
+        gsplat.isect_tiles(out_p[3].detach(), out_p[2], out_p[4].detach(), 16, TW, TH, packed=True, n_cameras=C,
+                           camera_ids=cam + 1)
+    e = gsplat.isect_tiles(out_p[3][:0].detach(), out_p[2][:0], out_p[4][:0].detach(), 16, TW, TH, packed=True,
+                           n_cameras=C, camera_ids=cam[:0])
+    assert all(t.numel() == 0 for t in e)
