@@ -178,7 +178,7 @@ def run_render(args, dev, rank, world):
     def step():
         out[0], views = render_trajectory(g["means"], g["quats"], g["scales"], g["opacities"], g["colors"], vm, Ks, W,
                                           H, sh_degree=3, views_per_call=args.views_per_call, rank=rank,
-                                          world_size=world, near_plane=0.1, out=out[0])
+                                          world_size=world, near_plane=0.1, out=out[0], streams=args.render_streams)
         return views
 
     for _ in range(max(1, args.warmup)):
@@ -207,7 +207,7 @@ def run_render(args, dev, rank, world):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[4]: {N} Gaussians, SH deg 3, {V}-view {W}x{H} trajectory, packed, no "
                                    f"gradients, views sharded over {world} rank(s) ({len(views)} on rank 0), "
-                                   f"{args.views_per_call} views per call, uint8 frames copied to pinned host memory; ego "
+                                   f"{args.views_per_call} views per call over {args.render_streams} stream(s), uint8 frames copied to pinned host memory; ego "
                                    f"path from x = {args.ego_x0} m, {empty} of rank 0's views empty",
                        "gaussians": N, "views": V, "width": W, "height": H,
                        "parallelism": f"view sharding x{world}, no collective" if world > 1 else "single GPU"}}),
@@ -287,12 +287,14 @@ def main():
     ap.add_argument("--height", type=int, default=None, help="default 375 (train, frames) / 1080 (render)")
     ap.add_argument("--frames", type=int, default=120)
     ap.add_argument("--views", type=int, default=600)
-    ap.add_argument("--views-per-call", type=int, default=4)
+    ap.add_argument("--views-per-call", type=int, default=8)
     ap.add_argument("--ego-x0", type=float, default=-30.0,
                     help="frames / render: x of the ego at frame 0 (the scene spans +-40 m, a 120-frame path is 60 m long)")
     ap.add_argument("--refine-interval", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=4)
+    ap.add_argument("--render-streams", type=int, default=2,
+                    help="--mode render: HIP streams that successive batches of views alternate over")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="multi-rank dry run on fewer GPUs than ranks: gloo backend, device = LOCAL_RANK %% device_count "
                          "(exercises the N > 1 code path on a one-GPU box; the number it prints is not a result)")

@@ -32,6 +32,15 @@ def test_trajectory_matches_per_view_calls(gpu_device):
                                     sh_degree=3, views_per_call=3, near_plane=0.1)
     assert rng == range(0, V) and frames.shape == (V, H, W, 3) and frames.dtype == torch.uint8 and frames.is_pinned()
     assert np.array_equal(frames.numpy(), np.stack(ref_u8))
+    # batches alternating over two and three HIP streams: the same bits, twice in a row (the second pass reuses the
+    # lanes' allocator pools), and the caller's stream may overwrite the inputs right behind the call
+    for n_streams in (2, 3):
+        for _ in range(2):
+            vm2, Ks2 = vm.clone(), Ks.clone()
+            fr, _ = render_trajectory(g["means"], g["quats"], g["scales"], g["opacities"], g["colors"], vm2, Ks2, W, H,
+                                      sh_degree=3, views_per_call=2, near_plane=0.1, streams=n_streams)
+            vm2.zero_(), Ks2.zero_()
+            assert np.array_equal(fr.numpy(), np.stack(ref_u8)), n_streams
     # float output, dense (unpacked) calls, two ranks
     parts = []
     for r in range(2):
