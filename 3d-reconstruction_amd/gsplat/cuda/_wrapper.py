@@ -1147,6 +1147,10 @@ def isect_tiles(means2d: Tensor, radii: Tensor, depths: Tensor, tile_size: int, 
     C, N = radii.shape
     assert means2d.shape == (C, N, 2) and depths.shape == (C, N), (means2d.shape, depths.shape)
     assert 0 < tile_width <= 0xFFFF and 0 < tile_height <= 0xFFFF
+    if C * N == 0:
+        return (torch.zeros(C, N, device=dev, dtype=torch.int32), torch.empty(0, device=dev, dtype=torch.int64),
+                torch.empty(0, device=dev, dtype=torch.int32))
+    assert C * N < 2 ** 31, "flat row ids are int32"
     with torch.no_grad():
         ts = float(tile_size)
         m = means2d.detach().to(torch.float32) / ts

@@ -121,6 +121,8 @@ def test_isect_tiles_and_offsets_bit_exact(gpu_device, tile_size):
     tiles, ids, fids = gsplat.isect_tiles(torch.zeros(2, 10, 2, device=dev), z.int(), z, 16, 4, 3)
     assert int(tiles.sum()) == 0 and ids.numel() == 0 and fids.numel() == 0
     assert int(gsplat.isect_offset_encode(ids, 2, 4, 3).abs().sum()) == 0
+    tiles, ids, fids = gsplat.isect_tiles(torch.zeros(2, 0, 2, device=dev), z[:, :0].int(), z[:, :0], 16, 4, 3)  # N = 0
+    assert tiles.shape == (2, 0) and ids.numel() == 0 and fids.numel() == 0
 
 
 def _stages(dev, W, H, C, N, D, seed=42):
