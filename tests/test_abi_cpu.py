@@ -268,3 +268,34 @@ def test_entry_points_reject_bad_arguments_before_any_launch():
     assert L.gs_sh_fwd(0, 16, 3, None, None, None, None, None) == 0
     assert L.gs_cube_texture_fwd(0, 8, 3, None, None, None, None, None) == 0
     assert L.gs_rigid_transform_fwd(0, 0, None, None, None, None, None, None, None, None) == 0
+
+
+def test_speculative_lists_protocol_on_the_host():
+    """gsplat.cuda._wrapper.SpecLists (device-side n_isects): what resolve() accepts and records, with the posted count
+    and the exact-size rebuild replaced by host stand-ins (no device work)."""
+    from gsplat.cuda import _wrapper as W
+
+    built = []
+
+    def make(capacity, posted, with_ids=True):
+        ids = torch.zeros(capacity, dtype=torch.int64) if with_ids else None
+        fids = torch.arange(capacity, dtype=torch.int32)
+        return W.SpecLists(capacity, None, ids, fids, torch.zeros(1, 2, 2, dtype=torch.int32), None,
+                           lambda: posted, lambda n, classes: built.append((n, tuple(classes))) or "rebuilt", ("k", capacity))
+
+    W._spec_table().clear()
+    s = make(100, (60, [0, 0, 3]))                       # fits: the lists are cut to the posted count
+    assert s.resolve() and s.n_isects == 60 and s.flatten_ids.shape == (60,) and s.isect_ids.shape == (60,)
+    assert W._spec_table()[("k", 100)] == (60, (0, 0, 3))
+    s = make(100, (101, [0, 0, 3]))                      # one entry too many: redone at the exact size
+    assert not s.resolve() and s.redo() == "rebuilt" and built[-1] == (101, (0, 0, 3))
+    assert W._spec_table()[("k", 100)] == (101, (0, 0, 3))   # ... and the next call of the shape is sized from it
+    s = make(100, (100, [0, 1, 0]))                      # exactly the capacity fits
+    assert s.resolve() and s.flatten_ids.shape == (100,)
+    s = make(100, (0, [0, 0, 0]))                        # nothing visible: the exact path builds the empty lists
+    assert not s.resolve()
+    s = make(100, (50, [2, 0, 0]), with_ids=True)        # a list above 2048 entries sorts through the key array: fine
+    assert s.resolve()
+    s = make(100, (50, [2, 0, 0]), with_ids=False)       # ... without it the speculative sort could not have sorted it
+    assert not s.resolve()
+    W._spec_table().clear()
