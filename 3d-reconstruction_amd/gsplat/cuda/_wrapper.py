@@ -623,7 +623,8 @@ def isect_tiles_binned(splats: Tensor, tiles_per_gauss: Tensor, tile_width: int,
         regions = min(SCATTER_REGIONS, tile_height)
     else:
         regions = min(max(1, T // 4000), tile_height) if STAGED_SCATTER else min(2, tile_height)
-    group = max(1, -(-(n_slices * C * regions) // SCATTER_WORKGROUPS))
+    # (a caller may ask for another workgroup count on its thread: the render-only harness, whose batches share the GPU)
+    group = max(1, -(-(n_slices * C * regions) // (getattr(_tls, "scatter_workgroups", 0) or SCATTER_WORKGROUPS)))
     vis_list = vis_cnt = vis_masks = None
     if REGION_SCATTER:
         seg = int(lib.gs_isect_bin_slice_rows(N, n_slices))

@@ -20,6 +20,9 @@ from .distributed import shard_views
 from .rendering import no_eval_cache, rasterization
 
 
+SCATTER_WORKGROUPS_SHARED = 128  # region-scatter workgroups when batches alternate over streams (render_trajectory)
+
+
 def frames_to_uint8(rgb: Tensor) -> Tensor:
     """video_utils.py:694-700: `rgb.clip(min=1e-6, max=1 - 1e-6)`, `(rgb * 255).astype(np.uint8)` (truncation), in one
     pass on the device (gs_frames_to_uint8)."""
@@ -64,8 +67,13 @@ def render_trajectory(means: Tensor, quats: Tensor, scales: Tensor, opacities: T
     lanes = [main] if streams == 1 else _lane_streams(dev, streams)
     from .cuda import _wrapper as W
 
-    prev_rows = getattr(W._tls, "sh_rows", 0)
+    prev_rows, prev_wg = getattr(W._tls, "sh_rows", 0), getattr(W._tls, "scatter_workgroups", 0)
     W._tls.sh_rows = 2  # neighbouring views: coefficient rows on demand, whatever views_per_call is (gs_proj_params.sh_rows)
+    if len(lanes) > 1 and not prev_wg:
+        # with another batch running beside it the region scatter does best on half the CUs (slice groups twice as
+        # long: longer runs per tile, and room for the other stream's kernels); 6 M Gaussians, 1920x1080, 8 views per
+        # call x 2 streams, views/s by workgroups: 64 1447, 96 1554, 128 1679, 192 1643, 256 1587, 512 1574
+        W._tls.scatter_workgroups = SCATTER_WORKGROUPS_SHARED
     try:
         for lane in lanes:
             if lane is not main:
@@ -73,7 +81,7 @@ def render_trajectory(means: Tensor, quats: Tensor, scales: Tensor, opacities: T
         _render_batches(means, quats, scales, opacities, colors, viewmats, Ks, width, height, sh_degree, views_per_call,
                         mine, n_mine, as_uint8, out, backgrounds, raster_kwargs, lanes, copy)
     finally:
-        W._tls.sh_rows = prev_rows
+        W._tls.sh_rows, W._tls.scatter_workgroups = prev_rows, prev_wg
         for lane in lanes:
             if lane is not main:
                 main.wait_stream(lane)  # (the caller may free or overwrite the inputs behind this call)
