@@ -20,6 +20,7 @@ from .distributed import shard_views
 from .rendering import no_eval_cache, rasterization
 
 
+SH_ROWS = 2  # neighbouring views: coefficient rows on demand, whatever views_per_call is (gs_proj_params.sh_rows)
 SCATTER_WORKGROUPS_SHARED = 128  # region-scatter workgroups when batches alternate over streams (render_trajectory)
 
 
@@ -68,7 +69,7 @@ def render_trajectory(means: Tensor, quats: Tensor, scales: Tensor, opacities: T
     from .cuda import _wrapper as W
 
     prev_rows, prev_wg = getattr(W._tls, "sh_rows", 0), getattr(W._tls, "scatter_workgroups", 0)
-    W._tls.sh_rows = 2  # neighbouring views: coefficient rows on demand, whatever views_per_call is (gs_proj_params.sh_rows)
+    W._tls.sh_rows = SH_ROWS
     if len(lanes) > 1 and not prev_wg:
         # with another batch running beside it the region scatter does best on half the CUs (slice groups twice as
         # long: longer runs per tile, and room for the other stream's kernels); 6 M Gaussians, 1920x1080, 8 views per

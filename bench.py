@@ -164,7 +164,12 @@ def run_render(args, dev, rank, world):
     converted to uint8 on the device and copied to pinned host memory behind the next batch's render
     (gsplat.harness.render_trajectory; the reference's loop is video_utils.py:647-706).  A step = one pass over the
     trajectory; value = all ranks' pixels / max-over-ranks time, D2H copy of the frames included."""
+    import gsplat.harness as harness
     from gsplat.harness import render_trajectory
+
+    for name in ("SH_ROWS", "SCATTER_WORKGROUPS_SHARED"):  # launch-shape sweeps
+        if os.environ.get("GS_HARNESS_" + name):
+            setattr(harness, name, int(os.environ["GS_HARNESS_" + name]))
 
     N, W, H, V = args.gaussians, args.width, args.height, args.views
     g = {k: v.to(dev) for k, v in synth_scene.make_gaussians(N, sh_degree=3, seed=42).items()}
